@@ -1,0 +1,268 @@
+// capi.cpp -- the extern "C" surface declared in include/genie_smem.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <new>
+
+#include "genie_internal.h"
+
+using namespace genie;
+
+namespace {
+
+int check_hip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return GENIE_OK;
+    set_hip_error(what, (int)e);
+    return GENIE_E_HIP;
+}
+
+int query_cus(int device)
+{
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    return cus;
+}
+
+int make_index(const uint8_t *codes, int64_t n, const int32_t *sa1, int32_t K, int32_t P, genie_index **out)
+{
+    if (!out) return GENIE_E_INVALID;
+    HostIndex *h = nullptr;
+    int rc = build_host_index(codes, n, sa1, K, P, &h);
+    if (rc) return rc;
+    genie_index *ix = new (std::nothrow) genie_index();
+    if (!ix) { delete h; return GENIE_E_NOMEM; }
+    ix->host = h;
+    fill_header(*h, &ix->hdr);
+    ix->has_hdr = true;
+    *out = ix;
+    return GENIE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int genie_abi_version(void) { return GENIE_ABI_VERSION; }
+
+int genie_index_create(const uint8_t *codes, int64_t n, int32_t K, int32_t dir_bits, genie_index **out)
+{
+    return make_index(codes, n, nullptr, K, dir_bits, out);
+}
+
+int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K,
+                               int32_t dir_bits, genie_index **out)
+{
+    if (!sa_one_based) return GENIE_E_INVALID;
+    return make_index(codes, n, sa_one_based, K, dir_bits, out);
+}
+
+int genie_index_set_rmi(genie_index *ix, int32_t nlev, const int32_t *sizes, const int32_t *scales,
+                        const double *coef, const double *icpt)
+{
+    if (!ix || !ix->host || ix->has_dev) return GENIE_E_INVALID;
+    if (nlev < 1 || nlev > GENIE_MAX_RMI_LEVELS || !sizes || !scales || !coef || !icpt) return GENIE_E_INVALID;
+    if (sizes[0] != 1) return GENIE_E_INVALID;
+    HostIndex &h = *ix->host;
+    int64_t tot = 0;
+    for (int l = 0; l < nlev; l++) {
+        if (sizes[l] < 1 || scales[l] < 1) return GENIE_E_INVALID;
+        if (l + 1 < nlev && sizes[l + 1] != scales[l]) return GENIE_E_INVALID;   // next level has `scale` experts
+        tot += sizes[l];
+    }
+    h.nlev = nlev;
+    int64_t off = 0;
+    for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
+        h.rmi_size[l] = l < nlev ? sizes[l] : 0;
+        h.rmi_scale[l] = l < nlev ? scales[l] : 0;
+        h.rmi_off[l] = (int32_t)off;
+        if (l < nlev) off += sizes[l];
+    }
+    h.rmi_off[GENIE_MAX_RMI_LEVELS] = (int32_t)off;
+    for (int l = nlev; l <= GENIE_MAX_RMI_LEVELS; l++) h.rmi_off[l] = (int32_t)tot;
+    h.rmi.resize((size_t)tot);
+    for (int64_t i = 0; i < tot; i++) h.rmi[(size_t)i] = RmiModel{coef[i], icpt[i]};
+    fill_header(h, &ix->hdr);
+    return GENIE_OK;
+}
+
+int genie_index_info(const genie_index *ix, genie_info *out)
+{
+    if (!ix || !out || !ix->has_hdr) return GENIE_E_INVALID;
+    out->n = ix->hdr.n;
+    out->K = ix->hdr.K;
+    out->dir_bits = ix->hdr.P;
+    out->lut_keys = ix->hdr.lut_keys;
+    out->lut_slots = ix->hdr.lut_slots;
+    out->rmi_levels = ix->hdr.nlev;
+    out->has_host = ix->host != nullptr;
+    out->has_device = ix->has_dev;
+    out->device = ix->device;
+    out->blob_bytes = ix->hdr.total_bytes;
+    return GENIE_OK;
+}
+
+const int32_t *genie_index_suffix_array(const genie_index *ix)
+{
+    return (ix && ix->host) ? ix->host->sa1.data() : nullptr;
+}
+
+int genie_index_lut_arrays(const genie_index *ix, const uint32_t **codes, const int32_t **lo, const int32_t **hi)
+{
+    if (!ix || !ix->host) return GENIE_E_INVALID;
+    if (codes) *codes = ix->host->lut_code.data();
+    if (lo) *lo = ix->host->lut_lo.data();
+    if (hi) *hi = ix->host->lut_hi.data();
+    return GENIE_OK;
+}
+
+int64_t genie_index_blob_bytes(const genie_index *ix)
+{
+    return (ix && ix->has_hdr) ? ix->hdr.total_bytes : (int64_t)GENIE_E_INVALID;
+}
+
+int genie_index_serialize(const genie_index *ix, void *host_dst, int64_t cap)
+{
+    if (!ix || !ix->host) return GENIE_E_INVALID;
+    return serialize(*ix->host, host_dst, cap);
+}
+
+int genie_index_open(const void *host_header, const void *d_blob, int64_t blob_bytes, int32_t device,
+                     genie_index **ix_inout)
+{
+    if (!host_header || !d_blob || !ix_inout) return GENIE_E_INVALID;
+    BlobHeader hdr;
+    memcpy(&hdr, host_header, sizeof(hdr));
+    DevIndex dev;
+    int rc = dev_index_from_header(hdr, d_blob, blob_bytes, &dev);
+    if (rc) return rc;
+    genie_index *ix = *ix_inout;
+    if (!ix) {
+        ix = new (std::nothrow) genie_index();
+        if (!ix) return GENIE_E_NOMEM;
+    }
+    ix->hdr = hdr;
+    ix->has_hdr = true;
+    ix->dev = dev;
+    ix->has_dev = true;
+    ix->device = device;
+    ix->blob_bytes = blob_bytes;
+    ix->num_cus = query_cus(device);
+    *ix_inout = ix;
+    return GENIE_OK;
+}
+
+int genie_index_to_device(genie_index *ix, int32_t device)
+{
+    if (!ix || !ix->host) return GENIE_E_INVALID;
+    int rc = check_hip(hipSetDevice(device), "hipSetDevice");
+    if (rc) return rc;
+    const int64_t bytes = ix->hdr.total_bytes;
+    void *host = malloc((size_t)bytes);
+    if (!host) return GENIE_E_NOMEM;
+    rc = serialize(*ix->host, host, bytes);
+    void *d = nullptr;
+    if (!rc) rc = check_hip(hipMalloc(&d, (size_t)bytes), "hipMalloc(index image)");
+    if (!rc) rc = check_hip(hipMemcpy(d, host, (size_t)bytes, hipMemcpyHostToDevice), "hipMemcpy(index image)");
+    if (!rc) {
+        if (ix->owned_blob) (void)hipFree(ix->owned_blob);
+        ix->owned_blob = d;
+        rc = genie_index_open(host, d, bytes, device, &ix);
+    } else if (d) {
+        (void)hipFree(d);
+    }
+    free(host);
+    return rc;
+}
+
+void genie_index_destroy(genie_index *ix)
+{
+    if (!ix) return;
+    if (ix->owned_blob) (void)hipFree(ix->owned_blob);
+    delete ix->host;
+    delete ix;
+}
+
+static int ready(const genie_index *ix)
+{
+    if (!ix) return GENIE_E_INVALID;
+    if (!ix->has_dev) return GENIE_E_NO_DEVICE;
+    return GENIE_OK;
+}
+
+int genie_sa_interval(const genie_index *ix, const uint8_t *d_pats, const int32_t *d_lens, int64_t N,
+                      int32_t stride, int32_t fixed_len, int32_t *d_out_lohi, void *stream)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    if (N < 0 || stride < 0 || fixed_len < 0 || (N > 0 && (!d_pats || !d_out_lohi))) return GENIE_E_INVALID;
+    if (fixed_len > GENIE_MAX_READ_LEN) return GENIE_E_TOO_LONG;
+    return launch_sa_interval(ix, d_pats, d_lens, N, stride, fixed_len, d_out_lohi, stream);
+}
+
+int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmers, int64_t N,
+                      int32_t *d_out_lohi, double *d_pred, void *stream)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    if (N < 0 || (N > 0 && (!d_kmers || !d_out_lohi))) return GENIE_E_INVALID;
+    if (ix->dev.K < 1) return GENIE_E_NO_LUT;
+    if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
+    return launch_seed_lookup(ix, mode, d_kmers, N, d_out_lohi, d_pred, stream);
+}
+
+int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
+                     int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
+                     int32_t *d_slots, int32_t cap, int32_t *d_status, void *stream)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    if (N < 0 || stride < 0 || fixed_len < 0 || cap < 1 || (N > 0 && (!d_reads || !d_counts || !d_slots)))
+        return GENIE_E_INVALID;
+    if (mode < GENIE_MODE_BWA || mode > GENIE_MODE_RMI) return GENIE_E_INVALID;
+    if (fixed_len > GENIE_MAX_READ_LEN) return GENIE_E_TOO_LONG;
+    if (mode != GENIE_MODE_BWA && ix->dev.K < 1) return GENIE_E_NO_LUT;
+    if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
+    if ((reinterpret_cast<uintptr_t>(d_slots) & 15) != 0) return GENIE_E_INVALID;
+    return launch_find_smems(ix, mode, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, cap,
+                             d_status, stream);
+}
+
+int64_t genie_compact_tmp_bytes(int64_t N) { return N < 0 ? (int64_t)GENIE_E_INVALID : compact_tmp_bytes(N); }
+
+int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap,
+                        int64_t *d_offsets, int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream)
+{
+    if (N < 0 || cap < 1 || !d_offsets || !d_tmp || (N > 0 && (!d_counts || !d_slots))) return GENIE_E_INVALID;
+    return launch_compact(d_counts, d_slots, N, cap, d_offsets, d_out, out_cap_rows, d_tmp, stream);
+}
+
+int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
+                      int32_t *lds_bytes)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    return find_smems_geometry(ix, mode, max_len, grid, block, lds_bytes);
+}
+
+const char *genie_strerror(int status)
+{
+    switch (status) {
+    case GENIE_OK: return "ok";
+    case GENIE_E_INVALID: return "invalid argument";
+    case GENIE_E_ALPHABET: return "base code outside 0..3";
+    case GENIE_E_NOMEM: return "out of host memory";
+    case GENIE_E_NO_DEVICE: return "index has no device image";
+    case GENIE_E_HIP: return "HIP runtime error";
+    case GENIE_E_TOO_LONG: return "read longer than the kernel supports";
+    case GENIE_E_NO_MODEL: return "no RMI model installed";
+    case GENIE_E_BAD_BLOB: return "not a serialized GENIE index";
+    case GENIE_E_NO_LUT: return "index built without a K-mer table (K = 0)";
+    case GENIE_E_CAPACITY: return "output capacity too small";
+    default: return "unknown status";
+    }
+}
+
+const char *genie_last_hip_error(void) { return last_hip_error(); }
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// genie_internal.h -- shared between the host index builder, the C ABI and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "genie_smem.h"
+
+namespace genie {
+
+constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
+constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kNoTail = 0xFFFFFFFFu;
+constexpr int kSectionAlign = 256;
+
+// One slot of the device K-mer hash table (the GPU form of the reference's `lut` dict,
+// SMEM/LUT.py:33-35): key -> inclusive SA interval.  Empty slot: lo < 0.
+struct LutSlot {
+    uint32_t key;
+    int32_t lo;
+    int32_t hi;
+    int32_t pad;
+};
+static_assert(sizeof(LutSlot) == 16, "LutSlot must be one 16-byte load");
+
+// One linear model of the RMI (sklearn LinearRegression with one feature, SMEM/RMI.py:23,40).
+struct RmiModel {
+    double coef;
+    double icpt;
+};
+
+// Two consecutive 32-base words of the packed reference, so that any 32-base window is ONE
+// aligned 16-byte load: rec[i] = { W[i], W[i+1] }.
+struct RefRec {
+    uint64_t w0;
+    uint64_t w1;
+};
+
+// Header at the start of a serialized index image (padded to GENIE_HEADER_BYTES).
+struct BlobHeader {
+    uint64_t magic;
+    uint32_t version;
+    uint32_t header_bytes;
+    int64_t total_bytes;
+    int64_t n;
+    int32_t K;
+    int32_t P;
+    int64_t off_sa;       // int32  [n+1]        0-based suffix starts, row 0 = n ('$')
+    int64_t off_ref;      // RefRec [ref_recs]   big-endian-in-word 2-bit bases, zero padded
+    int64_t off_dir;      // uint32 [4^P + 1]    prefix directory (rows < P-mer string)
+    int64_t off_lut;      // LutSlot[lut_slots]
+    int64_t off_rmi;      // RmiModel[rmi_models]
+    int64_t ref_recs;
+    int64_t dir_entries;
+    int64_t lut_slots;
+    int64_t lut_keys;
+    int64_t rmi_models;
+    int32_t nlev;
+    int32_t rmi_size[GENIE_MAX_RMI_LEVELS];
+    int32_t rmi_scale[GENIE_MAX_RMI_LEVELS];
+    int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1];
+    uint32_t padtail[8];  // padtail[l] = code(last l bases) << 2(P-l) for l < P, kNoTail if l > n
+};
+// The serialized header occupies GENIE_HEADER_BYTES; the struct is copied into its front.
+static_assert(sizeof(BlobHeader) <= GENIE_HEADER_BYTES, "header size");
+
+// What the kernels receive by value (kernarg): raw device pointers + scalars.
+struct DevIndex {
+    const int32_t *sa;
+    const RefRec *ref;
+    const uint32_t *dir;
+    const LutSlot *lut;
+    const RmiModel *rmi;
+    int32_t n;
+    int32_t K;
+    int32_t P;
+    int32_t dir_entries;
+    uint32_t lut_slots;
+    int32_t nlev;
+    int32_t rmi_scale[GENIE_MAX_RMI_LEVELS];
+    int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1];
+    uint32_t padtail[8];
+};
+
+inline uint32_t lut_hash(uint32_t code, uint32_t slots)
+{
+    return (uint32_t)(((uint64_t)(code * 0x9E3779B1u) * (uint64_t)slots) >> 32);
+}
+
+struct HostIndex {
+    int64_t n = 0;
+    int32_t K = 0, P = 0;
+    std::vector<uint8_t> codes;
+    std::vector<int32_t> sa0;            // 0-based starts, row 0 = n
+    std::vector<int32_t> sa1;            // reference convention (1-based), for the host API
+    std::vector<RefRec> ref;
+    std::vector<uint32_t> dir;
+    std::vector<uint32_t> lut_code;      // sorted distinct K-mers
+    std::vector<int32_t> lut_lo, lut_hi;
+    std::vector<LutSlot> lut_slots;
+    uint32_t padtail[8];
+    int32_t nlev = 0;
+    int32_t rmi_size[GENIE_MAX_RMI_LEVELS] = {0, 0, 0, 0};
+    int32_t rmi_scale[GENIE_MAX_RMI_LEVELS] = {0, 0, 0, 0};
+    int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1] = {0, 0, 0, 0, 0};
+    std::vector<RmiModel> rmi;
+};
+
+int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
+                     HostIndex **out);
+void fill_header(const HostIndex &h, BlobHeader *hdr);
+int serialize(const HostIndex &h, void *dst, int64_t cap);
+int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t bytes, DevIndex *out);
+
+}  // namespace genie
+
+struct genie_index {
+    genie::HostIndex *host = nullptr;
+    genie::BlobHeader hdr;
+    bool has_hdr = false;
+    genie::DevIndex dev;
+    bool has_dev = false;
+    int32_t device = -1;
+    void *owned_blob = nullptr;      // hipMalloc'ed by genie_index_to_device
+    int64_t blob_bytes = 0;
+    int32_t num_cus = 0;
+};
+
+// kernels.hip
+namespace genie {
+int launch_sa_interval(const genie_index *ix, const uint8_t *d_pats, const int32_t *d_lens, int64_t N,
+                       int32_t stride, int32_t fixed_len, int32_t *d_out, void *stream);
+int launch_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmers, int64_t N, int32_t *d_out,
+                       double *d_pred, void *stream);
+int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
+                      int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
+                      int32_t *d_slots, int32_t cap, int32_t *d_status, void *stream);
+int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap, int64_t *d_offsets,
+                   int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
+int64_t compact_tmp_bytes(int64_t N);
+int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
+                        int32_t *lds_bytes);
+void set_hip_error(const char *what, int code);
+const char *last_hip_error();
+}  // namespace genie

@@ -1,0 +1,265 @@
+// index_host.cpp -- host-side index construction and (de)serialization.
+//
+// Replaces the reference's O(n^2) index builders on this path:
+//   ExactMatch.create_bwt_matrix / create_fm_index   (reference SMEM/ExactMatch.py:22-68)
+//   LUT.generate_lut                                  (reference SMEM/LUT.py:15-35)
+// with: a suffix array by prefix doubling (O(n log^2 n)), a 2-bit packed reference, a P-mer
+// prefix directory, and the K-mer table read straight off the suffix-array order.  No BWT /
+// Occ matrix is built -- interval search on the suffix array yields the same row intervals as
+// FM backward search (pinned by tests against the reference's own outputs).
+#include <algorithm>
+#include <cstdlib>
+#include <new>
+
+#include "genie_internal.h"
+
+namespace genie {
+
+namespace {
+
+struct KeyIdx {
+    uint64_t key;
+    int32_t idx;
+};
+
+inline bool key_less(const KeyIdx &a, const KeyIdx &b) { return a.key < b.key; }
+
+// Suffix array of codes+"$" (n+1 rows, '$' smallest) by prefix doubling.
+// Round 0 ranks suffixes by their first 16 symbols (3 bits each: '$'/past-end = 0, base+1),
+// every later round sorts by (rank[i], rank[i+h]) and doubles h until all ranks are distinct.
+void build_suffix_array(const uint8_t *codes, int64_t n, std::vector<int32_t> &sa0)
+{
+    const int64_t rows = n + 1;
+    std::vector<KeyIdx> v((size_t)rows);
+    std::vector<int32_t> rank((size_t)rows), tmp((size_t)rows);
+    for (int64_t i = 0; i < rows; i++) {
+        uint64_t k = 0;
+        for (int j = 0; j < 16; j++) {
+            int64_t p = i + j;
+            k = (k << 3) | (p < n ? (uint64_t)codes[p] + 1 : 0);
+        }
+        v[(size_t)i] = {k, (int32_t)i};
+    }
+    std::sort(v.begin(), v.end(), key_less);
+    int64_t h = 16;
+    for (;;) {
+        int32_t r = 0;
+        for (int64_t i = 0; i < rows; i++) {
+            if (i > 0 && v[(size_t)i].key != v[(size_t)i - 1].key) r++;
+            tmp[(size_t)i] = r;
+        }
+        for (int64_t i = 0; i < rows; i++) rank[(size_t)v[(size_t)i].idx] = tmp[(size_t)i];
+        if (r == rows - 1) break;
+        for (int64_t i = 0; i < rows; i++) {
+            int32_t idx = v[(size_t)i].idx;
+            int64_t j = (int64_t)idx + h;
+            uint64_t second = j < rows ? (uint64_t)rank[(size_t)j] + 1 : 0;   // past the end sorts first
+            v[(size_t)i].key = ((uint64_t)rank[(size_t)idx] << 32) | second;
+        }
+        std::sort(v.begin(), v.end(), key_less);
+        h *= 2;
+    }
+    sa0.resize((size_t)rows);
+    for (int64_t i = 0; i < rows; i++) sa0[(size_t)i] = v[(size_t)i].idx;
+}
+
+// 32 bases per word, base j of the word in bits [62-2j, 63-2j]: unsigned integer order of two
+// windows == lexicographic order of the bases, clz(x^y)/2 == common prefix length.
+void pack_reference(const uint8_t *codes, int64_t n, std::vector<RefRec> &ref)
+{
+    const int64_t words = (n + 31) / 32 + 3;
+    std::vector<uint64_t> w((size_t)words + 1, 0);
+    for (int64_t i = 0; i < n; i++) w[(size_t)(i >> 5)] |= (uint64_t)codes[i] << (62 - 2 * (i & 31));
+    ref.resize((size_t)words);
+    for (int64_t i = 0; i < words; i++) ref[(size_t)i] = {w[(size_t)i], w[(size_t)i + 1]};
+}
+
+inline uint32_t code_at(const uint8_t *codes, int64_t s, int len)
+{
+    uint32_t c = 0;
+    for (int j = 0; j < len; j++) c = (c << 2) | codes[s + j];
+    return c;
+}
+
+// Is suffix a (0-based start) lexicographically smaller than suffix b?  ('$' smallest)
+bool suffix_less(const uint8_t *codes, int64_t n, int64_t a, int64_t b)
+{
+    int64_t la = n - a, lb = n - b, m = la < lb ? la : lb;
+    int c = m ? memcmp(codes + a, codes + b, (size_t)m) : 0;
+    if (c) return c < 0;
+    return la < lb;
+}
+
+}  // namespace
+
+int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
+                     HostIndex **out)
+{
+    if (!codes || !out || n < 1 || n > 0x7ffffff0ll || K < 0 || K > GENIE_MAX_K) return GENIE_E_INVALID;
+    if (P <= 0 || P > GENIE_MAX_DIR_BITS) P = GENIE_MAX_DIR_BITS;
+    for (int64_t i = 0; i < n; i++)
+        if (codes[i] > 3) return GENIE_E_ALPHABET;
+    HostIndex *h = new (std::nothrow) HostIndex();
+    if (!h) return GENIE_E_NOMEM;
+    try {
+        h->n = n;
+        h->K = K;
+        h->P = P;
+        h->codes.assign(codes, codes + n);
+        const int64_t rows = n + 1;
+        if (sa_one_based) {
+            // adopt the caller's suffix array after checking it is a sorted permutation
+            h->sa0.resize((size_t)rows);
+            std::vector<uint8_t> seen((size_t)rows, 0);
+            for (int64_t r = 0; r < rows; r++) {
+                int64_t s = (int64_t)sa_one_based[r] - 1;
+                if (s < 0 || s > n || seen[(size_t)s]) { delete h; return GENIE_E_INVALID; }
+                seen[(size_t)s] = 1;
+                h->sa0[(size_t)r] = (int32_t)s;
+            }
+            for (int64_t r = 1; r < rows; r++)
+                if (!suffix_less(codes, n, h->sa0[(size_t)r - 1], h->sa0[(size_t)r])) { delete h; return GENIE_E_INVALID; }
+        } else {
+            build_suffix_array(codes, n, h->sa0);
+        }
+        h->sa1.resize((size_t)rows);
+        for (int64_t r = 0; r < rows; r++) h->sa1[(size_t)r] = h->sa0[(size_t)r] + 1;
+        pack_reference(codes, n, h->ref);
+
+        // Prefix directory: dir[x] = number of rows whose suffix is lexicographically smaller
+        // than the P-mer string x (x = 4^P: all rows).  A row whose suffix holds >= P bases and
+        // starts with P-mer c is smaller than every x > c; a tail row t+"$" (fewer than P bases)
+        // is smaller than every x >= t padded with A's (t$ < tA...A).
+        const int64_t nb = (int64_t)1 << (2 * P);
+        std::vector<uint32_t> d((size_t)nb + 2, 0);
+        for (int64_t r = 0; r < rows; r++) {
+            int64_t s = h->sa0[(size_t)r], avail = n - s;
+            if (avail >= P) d[(size_t)code_at(codes, s, P) + 1]++;
+            else d[(size_t)((uint64_t)code_at(codes, s, (int)avail) << (2 * (P - avail)))]++;
+        }
+        h->dir.resize((size_t)nb + 1);
+        uint32_t acc = 0;
+        for (int64_t x = 0; x <= nb; x++) { acc += d[(size_t)x]; h->dir[(size_t)x] = acc; }
+        // padded codes of the tail suffixes (row 0 = '$' has length 0 and pads to 0)
+        for (int l = 0; l < 8; l++) {
+            if (l < P && l <= n) h->padtail[l] = code_at(codes, n - l, l) << (2 * (P - l));
+            else h->padtail[l] = kNoTail;
+        }
+
+        // K-mer table (LUT.generate_lut): rows sharing a K-mer prefix are contiguous in the SA.
+        if (K > 0 && n >= K) {
+            bool have = false;
+            uint32_t cur = 0;
+            for (int64_t r = 0; r < rows; r++) {
+                int64_t s = h->sa0[(size_t)r];
+                if (n - s < K) continue;
+                uint32_t c = code_at(codes, s, K);
+                if (!have || c != cur) {
+                    h->lut_code.push_back(c);
+                    h->lut_lo.push_back((int32_t)r);
+                    h->lut_hi.push_back((int32_t)r);
+                    cur = c;
+                    have = true;
+                } else {
+                    h->lut_hi.back() = (int32_t)r;
+                }
+            }
+            const uint64_t m = h->lut_code.size();
+            uint64_t slots = m + m / 2 + 8;                        // load factor <= 2/3
+            h->lut_slots.assign((size_t)slots, LutSlot{0, -1, -1, 0});
+            for (uint64_t i = 0; i < m; i++) {
+                uint32_t p = lut_hash(h->lut_code[(size_t)i], (uint32_t)slots);
+                while (h->lut_slots[p].lo >= 0) p = p + 1 == slots ? 0 : p + 1;
+                h->lut_slots[p] = LutSlot{h->lut_code[(size_t)i], h->lut_lo[(size_t)i], h->lut_hi[(size_t)i], 0};
+            }
+        } else {
+            h->lut_slots.assign(8, LutSlot{0, -1, -1, 0});
+        }
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return GENIE_E_NOMEM;
+    }
+    *out = h;
+    return GENIE_OK;
+}
+
+static int64_t align_up(int64_t x) { return (x + kSectionAlign - 1) / kSectionAlign * kSectionAlign; }
+
+void fill_header(const HostIndex &h, BlobHeader *hdr)
+{
+    memset(hdr, 0, sizeof(*hdr));
+    hdr->magic = kMagic;
+    hdr->version = kBlobVersion;
+    hdr->header_bytes = GENIE_HEADER_BYTES;
+    hdr->n = h.n;
+    hdr->K = h.K;
+    hdr->P = h.P;
+    hdr->ref_recs = (int64_t)h.ref.size();
+    hdr->dir_entries = (int64_t)h.dir.size();
+    hdr->lut_slots = (int64_t)h.lut_slots.size();
+    hdr->lut_keys = (int64_t)h.lut_code.size();
+    hdr->rmi_models = (int64_t)h.rmi.size();
+    hdr->nlev = h.nlev;
+    for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
+        hdr->rmi_size[l] = h.rmi_size[l];
+        hdr->rmi_scale[l] = h.rmi_scale[l];
+    }
+    for (int l = 0; l <= GENIE_MAX_RMI_LEVELS; l++) hdr->rmi_off[l] = h.rmi_off[l];
+    for (int l = 0; l < 8; l++) hdr->padtail[l] = h.padtail[l];
+    int64_t off = GENIE_HEADER_BYTES;
+    hdr->off_sa = off;
+    off = align_up(off + (int64_t)h.sa0.size() * 4);
+    hdr->off_ref = off;
+    off = align_up(off + (int64_t)h.ref.size() * (int64_t)sizeof(RefRec));
+    hdr->off_dir = off;
+    off = align_up(off + (int64_t)h.dir.size() * 4);
+    hdr->off_lut = off;
+    off = align_up(off + (int64_t)h.lut_slots.size() * (int64_t)sizeof(LutSlot));
+    hdr->off_rmi = off;
+    off = align_up(off + (int64_t)std::max<size_t>(h.rmi.size(), 1) * (int64_t)sizeof(RmiModel));
+    hdr->total_bytes = off;
+}
+
+int serialize(const HostIndex &h, void *dst, int64_t cap)
+{
+    BlobHeader hdr;
+    fill_header(h, &hdr);
+    if (!dst || cap < hdr.total_bytes) return GENIE_E_INVALID;
+    uint8_t *p = (uint8_t *)dst;
+    memset(p, 0, (size_t)hdr.total_bytes);
+    memcpy(p, &hdr, sizeof(hdr));
+    memcpy(p + hdr.off_sa, h.sa0.data(), h.sa0.size() * 4);
+    memcpy(p + hdr.off_ref, h.ref.data(), h.ref.size() * sizeof(RefRec));
+    memcpy(p + hdr.off_dir, h.dir.data(), h.dir.size() * 4);
+    memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
+    if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
+    return GENIE_OK;
+}
+
+int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t bytes, DevIndex *out)
+{
+    if (hdr.magic != kMagic || hdr.version != kBlobVersion || hdr.header_bytes != GENIE_HEADER_BYTES)
+        return GENIE_E_BAD_BLOB;
+    if (bytes < hdr.total_bytes || hdr.P < 1 || hdr.P > GENIE_MAX_DIR_BITS || hdr.n < 1) return GENIE_E_BAD_BLOB;
+    if (hdr.dir_entries != ((int64_t)1 << (2 * hdr.P)) + 1) return GENIE_E_BAD_BLOB;
+    if ((reinterpret_cast<uintptr_t>(d_blob) & 15) != 0) return GENIE_E_INVALID;
+    const uint8_t *p = (const uint8_t *)d_blob;
+    memset(out, 0, sizeof(*out));
+    out->sa = (const int32_t *)(p + hdr.off_sa);
+    out->ref = (const RefRec *)(p + hdr.off_ref);
+    out->dir = (const uint32_t *)(p + hdr.off_dir);
+    out->lut = (const LutSlot *)(p + hdr.off_lut);
+    out->rmi = (const RmiModel *)(p + hdr.off_rmi);
+    out->n = (int32_t)hdr.n;
+    out->K = hdr.K;
+    out->P = hdr.P;
+    out->dir_entries = (int32_t)hdr.dir_entries;
+    out->lut_slots = (uint32_t)hdr.lut_slots;
+    out->nlev = hdr.nlev;
+    for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) out->rmi_scale[l] = hdr.rmi_scale[l];
+    for (int l = 0; l <= GENIE_MAX_RMI_LEVELS; l++) out->rmi_off[l] = hdr.rmi_off[l];
+    for (int l = 0; l < 8; l++) out->padtail[l] = hdr.padtail[l];
+    return GENIE_OK;
+}
+
+}  // namespace genie

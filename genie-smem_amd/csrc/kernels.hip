@@ -1,0 +1,908 @@
+// kernels.hip -- gfx950 (MI355X, wave64) kernels of the batched SMEM finder.
+//
+// One wavefront per read.  Per read:
+//   phase 0  the read's bases are loaded coalesced, validated and packed 2 bits/base into LDS;
+//   phase 1  lane-parallel *matching statistics*: lane a computes fwd[a] = end of the longest
+//            prefix of read[a:] that occurs in the reference.  The seed is mode dependent --
+//            P-mer prefix directory (LDS) for BWA, K-mer hash table for LUT, RMI prediction
+//            (leaf coefficients in LDS) + last-mile search for RMI -- and is followed by a
+//            bounded binary search over suffix-array rows comparing 32 bases per 16-byte load
+//            of the packed reference (XOR + clz);
+//   phase 2  the reference's greedy traversal (get_SMEMS / get_smems_lut / get_smems_rmi) runs
+//            as a wave-uniform state machine over fwd[]; backward extension is a ballot-free
+//            lane-parallel max-reduction thanks to fwd[] being non-decreasing;
+//   phase 3  lane-parallel SA-interval search for every emitted SMEM and a 16-byte store of
+//            (start, end, lo, hi).
+// Pure integer / indexing work (one fp64 multiply-add per RMI level); no MFMA.
+//
+// The traversal is the *reduced form* of the reference's code; the
+// CPU oracle under oracle/ keeps the reference's original shape, so the two check each other.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <mutex>
+#include <string>
+
+#include "genie_internal.h"
+
+namespace genie {
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------ small wave helpers
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// LDS traffic between lanes of ONE wave: the LDS executes a wave's instructions in order, so
+// only the compiler has to be stopped from reordering.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ packed windows
+// 32 bases starting at base offset `pos`: base j of the window sits in bits [62-2j, 63-2j].
+__device__ __forceinline__ uint64_t funnel(uint64_t w0, uint64_t w1, int sh /* 0..62, even */)
+{
+    return sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0;
+}
+
+__device__ __forceinline__ uint64_t qwin(const uint64_t *qp, int pos)
+{
+    int i = pos >> 5;
+    return funnel(qp[i], qp[i + 1], (pos & 31) * 2);
+}
+
+__device__ __forceinline__ uint64_t rwin(const RefRec *ref, int pos)
+{
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(ref + (pos >> 5));   // one 16-byte load
+    return funnel(v.x, v.y, (pos & 31) * 2);
+}
+
+// ------------------------------------------------------------------ prefix directory (LDS)
+// dir[x] = number of SA rows whose suffix is smaller than the P-mer string x.  Rows whose
+// suffix has fewer than P bases ("tails", P-1 of them plus the '$' row) need the two
+// corrections below; padtail[l] is the A-padded code of the tail of length l.
+//
+// Rows with prefix `code` (m bases, 1 <= m <= P) are exactly [dir_lb, dir_ub).
+__device__ __forceinline__ uint32_t dir_lb(const DevIndex &ix, const uint32_t *dir, uint32_t code, int m)
+{
+    const uint32_t x = code << (2 * (ix.P - m));
+    uint32_t v = dir[x];
+    // tails  pat + A^t + '$'  (length l >= m) are >= pat but were counted as < x
+#pragma unroll
+    for (int l = 0; l < GENIE_MAX_DIR_BITS; l++)
+        if (l >= m && l < ix.P && ix.padtail[l] == x) v--;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t dir_ub(const DevIndex &ix, const uint32_t *dir, uint32_t code, int m)
+{
+    const uint32_t x = (code + 1) << (2 * (ix.P - m));
+    uint32_t v = dir[x];
+    // every tail sitting just below the next prefix is outside this prefix's rows
+#pragma unroll
+    for (int l = 1; l < GENIE_MAX_DIR_BITS; l++)
+        if (l < ix.P && ix.padtail[l] == x) v--;
+    return v;
+}
+
+// ------------------------------------------------------------------ suffix comparison
+struct Cmp {
+    int l;        // common prefix length of pattern q[a : a+m) and the suffix, capped at m
+    bool less;    // suffix < pattern  ('$' smallest; a suffix that has the pattern as prefix is not less)
+};
+
+// Compare q[a : a+m) with the reference suffix starting at 0-based s, the first `skip` bases
+// being known equal (skip <= min(m, n - s)).
+__device__ __forceinline__ Cmp cmp_suffix(const DevIndex &ix, const uint64_t *qp, int a, int m, int s, int skip)
+{
+    const int avail = ix.n - s;
+    const int lim = m < avail ? m : avail;
+    int l = skip;
+    bool less = false;
+    bool diff = false;
+    while (l < lim) {
+        const uint64_t xq = qwin(qp, a + l), xr = rwin(ix.ref, s + l);
+        const uint64_t x = xq ^ xr;
+        if (x) {
+            l += __clzll((long long)x) >> 1;
+            less = xr < xq;
+            diff = true;
+            break;
+        }
+        l += 32;
+    }
+    if (!diff || l >= lim) {      // ran off the pattern (prefix match) or off the reference ('$')
+        l = lim;
+        less = lim < m;
+    }
+    return {l, less};
+}
+
+// ------------------------------------------------------------------ seeds
+// LUT mode: `encoded_sub in self.lut.lut` + `self.lut.lut[encoded_sub][0]` (SMEM.py:65-70) as an
+// open-addressing probe of the K-mer hash table (one 16-byte slot per probe).
+__device__ __forceinline__ bool lut_probe(const DevIndex &ix, uint32_t code, int &lo, int &hi)
+{
+    uint32_t p = (uint32_t)(((uint64_t)(code * 0x9E3779B1u) * (uint64_t)ix.lut_slots) >> 32);
+    for (;;) {
+        const int4 v = *reinterpret_cast<const int4 *>(ix.lut + p);
+        if (v.y < 0) return false;
+        if ((uint32_t)v.x == code) { lo = v.y; hi = v.z; return true; }
+        p = p + 1 == ix.lut_slots ? 0 : p + 1;
+    }
+}
+
+// RMI.predict for one key (SMEM/RMI.py:52-69): per level p = coef*x + intercept, rounded after
+// the multiply and after the add (sklearn computes X @ coef_ + intercept_), next expert =
+// min(scale-1, max(0, int(p))).  `leaf` = last level's models staged in LDS (or nullptr).
+__device__ __forceinline__ double rmi_predict(const DevIndex &ix, const RmiModel *leaf, uint32_t code)
+{
+    const double x = (double)code;
+    double p = 0.0;
+    int idx = 0;
+    for (int l = 0; l < ix.nlev; l++) {
+        double2 m;
+        if (leaf && l == ix.nlev - 1) m = *reinterpret_cast<const double2 *>(leaf + idx);        // LDS
+        else m = *reinterpret_cast<const double2 *>(ix.rmi + ix.rmi_off[l] + idx);               // global
+        p = __dadd_rn(__dmul_rn(m.x, x), m.y);
+        const int scale = ix.rmi_scale[l];
+        idx = !(p > 0.0) ? 0 : (p >= (double)scale ? scale - 1 : (int)p);
+    }
+    return p;
+}
+
+// K-mer `code` against the suffix of SA row r, over K symbols with '$' smallest:
+// -1 suffix < kmer, 0 kmer is a prefix of the suffix, +1 suffix > kmer.
+__device__ __forceinline__ int kmer_cmp_row(const DevIndex &ix, int r, uint32_t code)
+{
+    const int s = ix.sa[r];
+    const int avail = ix.n - s;
+    if (avail == 0) return -1;
+    const uint64_t w = rwin(ix.ref, s);
+    if (avail >= ix.K) {
+        const uint32_t rc = (uint32_t)(w >> (64 - 2 * ix.K));
+        return rc < code ? -1 : (rc > code ? 1 : 0);
+    }
+    const uint32_t rc = (uint32_t)(w >> (64 - 2 * avail));
+    const uint32_t qc = code >> (2 * (ix.K - avail));
+    return rc <= qc ? -1 : 1;          // equal so far: the suffix ends ('$') first
+}
+
+// RMI_LUT.get_suffix_rmi (SMEM/RMI_LUT.py:67-78): predict a row, then the last-mile search --
+// gallop out from the predicted row to bracket the K-mer, then bound-search inside the bracket.
+// Contract behaviour: always the TRUE interval; hit <=> lo <= hi.
+__device__ __forceinline__ bool rmi_lookup(const DevIndex &ix, const RmiModel *leaf, uint32_t code, int &lo, int &hi,
+                                           double *pred_out)
+{
+    const double p = rmi_predict(ix, leaf, code);
+    if (pred_out) *pred_out = p;
+    const int rows = ix.n + 1;
+    const int r0 = !(p > 0.0) ? 0 : (p >= (double)rows ? rows - 1 : (int)p);     // int(start_sa), clamped
+    // bracket the first row that is not smaller than the K-mer: rows < L are smaller, row R is not
+    int L, R;
+    if (kmer_cmp_row(ix, r0, code) < 0) {
+        L = r0 + 1;
+        R = rows;
+        for (int step = 1;; step <<= 1) {
+            const int pr = r0 + step;
+            if (pr >= rows) break;
+            if (kmer_cmp_row(ix, pr, code) < 0) L = pr + 1;
+            else { R = pr; break; }
+        }
+    } else {
+        R = r0;
+        L = 0;
+        for (int step = 1;; step <<= 1) {
+            const int pr = r0 - step;
+            if (pr < 0) break;
+            if (kmer_cmp_row(ix, pr, code) < 0) { L = pr + 1; break; }
+            R = pr;
+        }
+    }
+    while (L < R) {
+        const int mid = (L + R) >> 1;
+        if (kmer_cmp_row(ix, mid, code) < 0) L = mid + 1; else R = mid;
+    }
+    const int first = L;
+    if (first >= rows || kmer_cmp_row(ix, first, code) != 0) { lo = first; hi = first - 1; return false; }
+    // last row that still has the K-mer as prefix: gallop right, then bisect
+    int a = first, b = rows;                       // row a matches, row b does not (or is past the end)
+    for (int step = 1;; step <<= 1) {
+        const int pr = first + step;
+        if (pr >= rows) break;
+        if (kmer_cmp_row(ix, pr, code) == 0) a = pr;
+        else { b = pr; break; }
+    }
+    while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (kmer_cmp_row(ix, mid, code) == 0) a = mid; else b = mid;
+    }
+    lo = first;
+    hi = a;
+    return true;
+}
+
+// ------------------------------------------------------------------ matching statistics
+// Longest prefix of q[a:L) that occurs in the reference (its length), by bounded binary search
+// over the SA rows [lo, hi) that all share the first `skip` bases with the pattern.
+__device__ __forceinline__ int ms_search(const DevIndex &ix, const uint64_t *qp, int a, int m, int lo, int hi, int skip)
+{
+    int best = skip;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const Cmp c = cmp_suffix(ix, qp, a, m, ix.sa[mid], skip);
+        best = c.l > best ? c.l : best;
+        if (c.less) lo = mid + 1; else hi = mid;
+    }
+    return best;
+}
+
+// Generic path: P-mer directory bucket, then ms_search; shorter than P bases => directory only.
+__device__ __forceinline__ int ms_generic(const DevIndex &ix, const uint32_t *dir, const uint64_t *qp, int a, int L)
+{
+    const int m = L - a;
+    const int P = ix.P;
+    const uint64_t w = qwin(qp, a);
+    int t = m;
+    if (m >= P) {
+        const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
+        const int lo = (int)dir[b];                                   // == dir_lb(b, P)
+        const int hi = (int)dir_ub(ix, dir, b, P);
+        if (lo < hi) return ms_search(ix, qp, a, m, lo, hi, P);
+        t = P - 1;
+    }
+    for (; t >= 1; --t) {
+        const uint32_t code = (uint32_t)(w >> (64 - 2 * t));
+        if (dir_lb(ix, dir, code, t) < dir_ub(ix, dir, code, t)) return t;
+    }
+    return 0;
+}
+
+// Inclusive SA interval of q[a : a+m) (== ExactMatch.exact_match_back_prop of that substring);
+// (-1,-1) if absent, (0,n) for the empty pattern.
+__device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *dir, const uint64_t *qp, int a, int m)
+{
+    if (m == 0) return make_int2(0, ix.n);
+    const int P = ix.P;
+    const uint64_t w = qwin(qp, a);
+    if (m <= P) {
+        const uint32_t code = (uint32_t)(w >> (64 - 2 * m));
+        const int lb = (int)dir_lb(ix, dir, code, m), ub = (int)dir_ub(ix, dir, code, m);
+        return lb < ub ? make_int2(lb, ub - 1) : make_int2(-1, -1);
+    }
+    const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
+    int lo = (int)dir[b];
+    const int hi = (int)dir_ub(ix, dir, b, P);
+    int h = hi;
+    while (lo < h) {                                    // first row whose suffix is not < pattern
+        const int mid = (lo + h) >> 1;
+        if (cmp_suffix(ix, qp, a, m, ix.sa[mid], P).less) lo = mid + 1; else h = mid;
+    }
+    const int first = lo;
+    h = hi;
+    while (lo < h) {                                    // first row that no longer has it as prefix
+        const int mid = (lo + h) >> 1;
+        if (cmp_suffix(ix, qp, a, m, ix.sa[mid], P).l >= m) lo = mid + 1; else h = mid;
+    }
+    return first < lo ? make_int2(first, lo - 1) : make_int2(-1, -1);
+}
+
+// ------------------------------------------------------------------ per-wave scratch in LDS
+struct WaveScratch {
+    uint64_t *qp;      // packed read, (Lmax+31)/32 + 2 words, zero padded
+    uint16_t *fwd;     // fwd[a], a in [0, L]
+    uint32_t *emit;    // emitted SMEMs: start | end << 16   (aliases the raw code bytes of phase 0)
+};
+
+__host__ __device__ inline int scratch_qp_bytes(int Lmax) { return (((Lmax + 31) / 32 + 2) * 8 + 15) & ~15; }
+__host__ __device__ inline int scratch_fwd_bytes(int Lmax) { return ((Lmax + 2) * 2 + 15) & ~15; }
+__host__ __device__ inline int scratch_emit_bytes(int Lmax) { return (Lmax * 4 + 15) & ~15; }
+__host__ __device__ inline int scratch_bytes(int Lmax)
+{
+    return scratch_qp_bytes(Lmax) + scratch_fwd_bytes(Lmax) + scratch_emit_bytes(Lmax);
+}
+
+__device__ __forceinline__ WaveScratch carve(uint8_t *base, int Lmax)
+{
+    WaveScratch s;
+    s.qp = reinterpret_cast<uint64_t *>(base);
+    s.fwd = reinterpret_cast<uint16_t *>(base + scratch_qp_bytes(Lmax));
+    s.emit = reinterpret_cast<uint32_t *>(base + scratch_qp_bytes(Lmax) + scratch_fwd_bytes(Lmax));
+    return s;
+}
+
+// Phase 0: coalesced byte loads, validation, 2-bit packing.  Returns false on a code > 3.
+__device__ __forceinline__ bool load_and_pack(const uint8_t *src, int L, int Lmax, const WaveScratch &ws, int lane)
+{
+    uint8_t *raw = reinterpret_cast<uint8_t *>(ws.emit);
+    bool bad = false;
+    for (int i = lane; i < L; i += kWave) {
+        const uint8_t c = src[i];
+        bad |= c > 3;
+        raw[i] = c;
+    }
+    wave_lds_fence();
+    const int nw = (L + 31) / 32 + 2;
+    for (int wi = lane; wi < nw; wi += kWave) {
+        uint64_t w = 0;
+        const int b0 = wi * 32;
+        const int cnt = L - b0 < 32 ? L - b0 : 32;
+        for (int j = 0; j < cnt; j++) w |= (uint64_t)(raw[b0 + j] & 3) << (62 - 2 * j);
+        ws.qp[wi] = w;
+    }
+    wave_lds_fence();
+    return !__any(bad);
+}
+
+// ------------------------------------------------------------------ traversal (wave-uniform)
+struct Cand {
+    int len, k, j;
+};
+
+// SMEM.backward_extension (SMEM.py:389-423) for forward matches whose right ends are the
+// contiguous range [jmin, jmax] from `start`: for every j the leftmost k with q[k:j) present;
+// longest wins, ties to the smallest j (strict `>` in ascending key order, :413); finally the
+// longest forward match if strictly longer (:418-421).  fwd[] is non-decreasing, so
+// k(j) = min{k : fwd[k] >= j} and the best over j equals max_k (min(fwd[k], jmax) - k) over
+// k < start with fwd[k] >= jmin -- one lane per k and a wave max.  M = longest match in the read
+// bounds how far left k can be.
+__device__ __forceinline__ Cand back_ext(const uint16_t *fwd, int start, int jmin, int jmax, int M, int lane)
+{
+    uint32_t best = 0;
+    int klo = jmin - M;
+    klo = klo < 0 ? 0 : klo;
+    for (int k0 = klo; k0 < start; k0 += kWave) {
+        const int k = k0 + lane;
+        uint32_t key = 0;
+        if (k < start) {
+            const int f = fwd[k];
+            if (f >= jmin) {
+                const int j = f < jmax ? f : jmax;
+                key = ((uint32_t)(j - k) << 16) | (uint32_t)(0xFFFF - j);
+            }
+        }
+        best = key > best ? key : best;
+    }
+    best = rflu(wave_max_u32(best));
+    Cand c;
+    c.len = (int)(best >> 16);
+    c.j = 0xFFFF - (int)(best & 0xFFFF);
+    c.k = c.j - c.len;
+    if (jmax - start > c.len) { c.len = jmax - start; c.k = start; c.j = jmax; }
+    return c;
+}
+
+// SMEM.check_sequential on the position lists of the K-mers at read offsets c (current frame)
+// and pc (previous frame) (SMEM.py:75, 196-202 / 262-265): is there an occurrence p of the
+// current K-mer with the previous K-mer at p+1?  For adjacent frames (pc == c+1) this is
+// "the (K+1)-mer q[c : c+K+1) occurs"; the reference can also ask it for non-adjacent frames
+// (stale prev_frame after the `continue` at SMEM.py:94-95) -- then it is a positional test.
+__device__ __forceinline__ bool seq_check(const DevIndex &ix, const uint32_t *dir, const WaveScratch &ws, int c, int pc,
+                                          int lane)
+{
+    const int K = ix.K;
+    if (pc == c + 1) return rfl((int)ws.fwd[c]) >= c + K + 1;
+    const int2 iv = sa_interval(ix, dir, ws.qp, c, K);             // wave-uniform inputs
+    if (iv.x < 0) return false;
+    const uint32_t want = (uint32_t)(qwin(ws.qp, pc) >> (64 - 2 * K));
+    bool found = false;
+    for (int r0 = iv.x; r0 <= iv.y; r0 += kWave) {
+        const int r = r0 + lane;
+        bool ok = false;
+        if (r <= iv.y) {
+            const int s1 = ix.sa[r] + 1;
+            if (s1 + K <= ix.n) ok = (uint32_t)(rwin(ix.ref, s1) >> (64 - 2 * K)) == want;
+        }
+        found |= __any(ok) != 0;
+    }
+    return found;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) find_smems_kernel(DevIndex ix, const uint8_t *__restrict__ reads,
+                                                           const int32_t *__restrict__ lens, long long N, int stride,
+                                                           int fixed_len, int Lmax, int min_len,
+                                                           int32_t *__restrict__ counts, int4 *__restrict__ slots,
+                                                           int cap, int32_t *__restrict__ status, int leaf_in_lds)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+
+    // ---- stage the read-only seed tables in LDS (once per persistent block)
+    uint32_t *dir = reinterpret_cast<uint32_t *>(smem);
+    const int dir_bytes = (ix.dir_entries * 4 + 15) & ~15;
+    for (int i = threadIdx.x; i < ix.dir_entries; i += blockDim.x) dir[i] = ix.dir[i];
+    const RmiModel *leaf = nullptr;
+    int leaf_bytes = 0;
+    if (MODE == GENIE_MODE_RMI && leaf_in_lds) {
+        const int l0 = ix.rmi_off[ix.nlev - 1], cnt = ix.rmi_off[ix.nlev] - l0;
+        double2 *dst = reinterpret_cast<double2 *>(smem + dir_bytes);
+        const double2 *src = reinterpret_cast<const double2 *>(ix.rmi + l0);
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+        leaf = reinterpret_cast<const RmiModel *>(dst);
+        leaf_bytes = cnt * 16;
+    }
+    __syncthreads();
+
+    const WaveScratch ws = carve(smem + dir_bytes + leaf_bytes + wave * scratch_bytes(Lmax), Lmax);
+    const int K = ix.K;
+
+    for (long long r = (long long)blockIdx.x * waves_per_block + wave; r < N;
+         r += (long long)gridDim.x * waves_per_block) {
+        const int L = lens ? lens[r] : fixed_len;
+        int st = GENIE_READ_OK;
+        int cnt = 0;
+        if (L > Lmax || L < 0) {
+            st = GENIE_READ_BAD_BASE;                  // host validates lengths; defensive only
+        } else if (!load_and_pack(reads + r * (long long)stride, L, Lmax, ws, lane)) {
+            st = GENIE_READ_BAD_BASE;
+        } else if (MODE != GENIE_MODE_BWA && L < K) {
+            st = GENIE_READ_TOO_SHORT;
+        }
+
+        if (st == GENIE_READ_OK && L > 0) {
+            // ---------------- phase 1: fwd[a] for every a, one lane per position
+            int mymax = 0;
+            for (int a = lane; a < L; a += kWave) {
+                int len = 0;
+                bool seeded = false;
+                if (MODE != GENIE_MODE_BWA && a + K <= L) {
+                    const uint32_t code = (uint32_t)(qwin(ws.qp, a) >> (64 - 2 * K));
+                    int lo, hi;
+                    const bool hit = MODE == GENIE_MODE_LUT ? lut_probe(ix, code, lo, hi)
+                                                            : rmi_lookup(ix, leaf, code, lo, hi, nullptr);
+                    if (hit) {                         // forward extension from the seed interval
+                        len = ms_search(ix, ws.qp, a, L - a, lo, hi + 1, K);
+                        seeded = true;
+                    }
+                }
+                if (!seeded) len = ms_generic(ix, dir, ws.qp, a, L);
+                ws.fwd[a] = (uint16_t)(a + len);
+                mymax = len > mymax ? len : mymax;
+            }
+            if (lane == 0) ws.fwd[L] = (uint16_t)L;
+            const int M = (int)rflu(wave_max_u32((uint32_t)mymax));
+            wave_lds_fence();
+
+            // ---------------- phase 2: the reference's traversal, wave-uniform
+            const uint16_t *fwd = ws.fwd;
+#define FWD(i) rfl((int)fwd[(i)])
+#define EMIT(kk, jj)                                                          \
+    do {                                                                      \
+        if (lane == 0 && cnt < Lmax) ws.emit[cnt] = (uint32_t)(kk) | ((uint32_t)(jj) << 16); \
+        cnt++;                                                                \
+    } while (0)
+
+            if (MODE == GENIE_MODE_BWA) {
+                // SMEM.get_SMEMS (SMEM.py:456-467): i = 0; smem at i; i = its end
+                int i = 0;
+                while (i < L) {
+                    const int f = FWD(i);
+                    if (f == i) { st = GENIE_READ_ABSENT_BASE; break; }
+                    const Cand c = back_ext(fwd, i, i + 1, f, M, lane);      // get_SMEM_at_index :469-484
+                    if (c.len >= min_len) EMIT(c.k, c.j);
+                    i = c.j;
+                }
+            } else {
+                // SMEM.get_smems_lut / get_smems_rmi (SMEM.py:20-192 / 206-384)
+                const int f0 = FWD(0);
+                if (f0 == 0) {
+                    st = GENIE_READ_ABSENT_BASE;
+                } else {
+                    EMIT(0, f0);                                             // first SMEM (:26-39)
+                    int end = f0, prev_len = f0;
+                    while (end < L && st == GENIE_READ_OK) {                 // :49
+                        int pstate = 0, pc = 0;                              // 0 None, 1 (), 2 frame
+                        bool pfwd = false, have = false;
+                        Cand cur = {0, 0, 0};
+                        const int prev_start = end - prev_len;
+#define OFFER(LEN, KK, JJ)                                                    \
+    do {                                                                      \
+        if (!have || (LEN) >= cur.len) { cur.len = (LEN); cur.k = (KK); cur.j = (JJ); have = true; } \
+    } while (0)
+                        for (int i = 0; i < K; i++) {                        // :56
+                            if (i >= prev_len) break;                        // :57 (monotone in i)
+                            const int c = end - i;
+                            if (c + K > L) continue;                         // :62
+                            const int fc = FWD(c);
+                            if (fc >= c + K) {                               // seed hit (:67 / :253)
+                                if (pstate == 0) { pstate = 2; pc = c; pfwd = true; }
+                                else if (pstate == 1) { pstate = 2; pc = c; pfwd = false; }
+                                else {
+                                    const int fp = FWD(pc);
+                                    if (seq_check(ix, dir, ws, c, pc, lane)) {               // Case 1 (:75)
+                                        if (pfwd) {
+                                            const Cand b = back_ext(fwd, pc, pc + K, fp, M, lane);
+                                            OFFER(b.len, b.k, b.j);
+                                        } else {
+                                            if (have && (pc - prev_start) + K < cur.len) continue;   // :94-95
+                                            const Cand b = back_ext(fwd, pc, pc + K, pc + K, M, lane);
+                                            OFFER(b.len, b.k, b.j);
+                                        }
+                                    } else {                                                  // Case 2 (:108)
+                                        if (pfwd) OFFER(fp - pc, pc, fp);
+                                        else OFFER(K, c, c + K);                              // current K-mer (:119-122)
+                                    }
+                                    pc = c;
+                                    pfwd = false;
+                                }
+                            } else {                                                          // seed miss
+                                if (pstate == 2) {                                            // Case 3 (:129)
+                                    if (pfwd) { const int fp = FWD(pc); OFFER(fp - pc, pc, fp); }
+                                    else OFFER(K, pc, pc + K);
+                                }
+                                pstate = 1;
+                            }
+                        }
+                        if (pstate == 2) {                                                    // last frame (:149)
+                            const int fp = FWD(pc);
+                            const Cand b = pfwd ? back_ext(fwd, pc, pc + K, fp, M, lane)
+                                                : back_ext(fwd, pc, pc + K, pc + K, M, lane);
+                            OFFER(b.len, b.k, b.j);
+                        }
+                        if (!have) {                                                          // :175 BWA step
+                            const int f = FWD(end);
+                            if (f == end) { st = GENIE_READ_ABSENT_BASE; break; }
+                            cur = back_ext(fwd, end, end + 1, f, M, lane);
+                        }
+                        EMIT(cur.k, cur.j);
+                        end = cur.j;
+                        prev_len = cur.len;
+#undef OFFER
+                    }
+                }
+            }
+#undef EMIT
+#undef FWD
+            if (st != GENIE_READ_OK) cnt = 0;
+            wave_lds_fence();
+
+            // ---------------- phase 3: SA interval of every emitted SMEM, one lane each
+            const int nout = cnt < cap ? cnt : cap;
+            for (int t = lane; t < nout; t += kWave) {
+                const uint32_t e = ws.emit[t];
+                const int k = (int)(e & 0xFFFF), j = (int)(e >> 16);
+                const int2 iv = sa_interval(ix, dir, ws.qp, k, j - k);
+                slots[r * (long long)cap + t] = make_int4(k, j, iv.x, iv.y);
+            }
+            if (cnt > cap) st = GENIE_READ_OVERFLOW;
+            wave_lds_fence();
+        }
+        if (lane == 0) {
+            counts[r] = cnt;
+            if (status) status[r] = st;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K1: batched exact_match_back_prop
+__global__ void __launch_bounds__(256) sa_interval_kernel(DevIndex ix, const uint8_t *__restrict__ pats,
+                                                          const int32_t *__restrict__ lens, long long N, int stride,
+                                                          int fixed_len, int Lmax, int2 *__restrict__ out)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    uint32_t *dir = reinterpret_cast<uint32_t *>(smem);
+    const int dir_bytes = (ix.dir_entries * 4 + 15) & ~15;
+    for (int i = threadIdx.x; i < ix.dir_entries; i += blockDim.x) dir[i] = ix.dir[i];
+    __syncthreads();
+    const WaveScratch ws = carve(smem + dir_bytes + wave * scratch_bytes(Lmax), Lmax);
+    for (long long r = (long long)blockIdx.x * waves_per_block + wave; r < N;
+         r += (long long)gridDim.x * waves_per_block) {
+        const int L = lens ? lens[r] : fixed_len;
+        int2 iv = make_int2(-2, -2);
+        if (L >= 0 && L <= Lmax && load_and_pack(pats + r * (long long)stride, L, Lmax, ws, lane))
+            iv = sa_interval(ix, dir, ws.qp, 0, L);          // every lane computes the same interval
+        if (lane == 0) out[r] = iv;
+        wave_lds_fence();
+    }
+}
+
+// ------------------------------------------------------------------ batched seed lookup (A6 / A8)
+template <int MODE>
+__global__ void __launch_bounds__(256) seed_lookup_kernel(DevIndex ix, const uint8_t *__restrict__ kmers, long long N,
+                                                          int2 *__restrict__ out, double *__restrict__ pred)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int K = ix.K;
+    uint32_t code = 0;
+    bool bad = false;
+    for (int j = 0; j < K; j++) {
+        const uint8_t c = kmers[i * K + j];
+        bad |= c > 3;
+        code = (code << 2) | (c & 3);
+    }
+    int lo = -1, hi = -1;
+    double p = 0.0;
+    if (bad) {
+        lo = hi = -2;
+    } else if (MODE == GENIE_MODE_LUT) {
+        if (!lut_probe(ix, code, lo, hi)) lo = hi = -1;
+    } else {
+        rmi_lookup(ix, nullptr, code, lo, hi, &p);      // absent keeps the reference's lower > upper
+    }
+    out[i] = make_int2(lo, hi);
+    if (pred) pred[i] = p;
+}
+
+// ------------------------------------------------------------------ compaction to CSR
+constexpr int kScanBlock = 1024;
+
+__global__ void __launch_bounds__(kScanBlock) compact_block_sums(const int32_t *__restrict__ counts, long long N, int cap,
+                                                                 unsigned long long *__restrict__ block_sums)
+{
+    __shared__ unsigned int wsum[kScanBlock / kWave];
+    const long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
+    unsigned int v = 0;
+    if (i < N) { const int c = counts[i]; v = (unsigned)(c < 0 ? 0 : (c < cap ? c : cap)); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (unsigned)__shfl_xor((int)v, off, kWave);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kScanBlock / kWave; w++) s += wsum[w];
+        block_sums[blockIdx.x] = s;
+    }
+}
+
+// single block: exclusive scan of the block sums in place (+ grand total at [nblocks])
+__global__ void __launch_bounds__(kScanBlock) compact_scan_sums(unsigned long long *__restrict__ block_sums, long long nblocks)
+{
+    __shared__ unsigned long long part[kScanBlock];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < nblocks; base += kScanBlock) {
+        const long long i = base + threadIdx.x;
+        const unsigned long long v = i < nblocks ? block_sums[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlock; off <<= 1) {           // Hillis-Steele inclusive scan
+            unsigned long long add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += part[kScanBlock - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[nblocks] = carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock) compact_scatter(const int32_t *__restrict__ counts,
+                                                              const int4 *__restrict__ slots, long long N, int cap,
+                                                              const unsigned long long *__restrict__ block_sums,
+                                                              long long *__restrict__ offsets, int4 *__restrict__ out,
+                                                              long long out_cap_rows, int *__restrict__ overflow)
+{
+    __shared__ unsigned int part[kScanBlock];
+    const long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
+    unsigned int v = 0;
+    if (i < N) { const int c = counts[i]; v = (unsigned)(c < 0 ? 0 : (c < cap ? c : cap)); }
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        unsigned int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const unsigned long long base = block_sums[blockIdx.x] + part[threadIdx.x] - v;
+    if (i < N) {
+        offsets[i] = (long long)base;
+        if (i == N - 1) offsets[N] = (long long)(base + v);
+        if (!out) {
+            /* offsets only */
+        } else if ((long long)(base + v) > out_cap_rows) {
+            *overflow = 1;
+        } else {
+            for (unsigned int t = 0; t < v; t++) out[base + t] = slots[i * (long long)cap + t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side: launch plumbing
+std::mutex g_err_mu;
+std::string g_err;
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) { set_hip_error(#expr, (int)e_); return GENIE_E_HIP; } \
+    } while (0)
+
+struct Geometry {
+    int grid, block, lds, leaf_in_lds, Lmax;
+};
+
+int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
+{
+    const DevIndex &d = ix->dev;
+    const int dir_bytes = (d.dir_entries * 4 + 15) & ~15;
+    const int lds_cap = 160 * 1024;
+    int leaf_bytes = 0;
+    if (mode == GENIE_MODE_RMI) {
+        const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
+        if (cnt * 16 <= 48 * 1024) leaf_bytes = cnt * 16;
+    }
+    const int Lmax = std::max(32, (max_len + 31) / 32 * 32);
+    const int per_wave = scratch_bytes(Lmax);
+    int waves = (lds_cap - dir_bytes - leaf_bytes) / per_wave;
+    if (waves < 1) return GENIE_E_TOO_LONG;
+    if (waves > 16) waves = 16;
+    int w2 = 1;
+    while (w2 * 2 <= waves) w2 *= 2;
+    waves = w2;
+    const int lds = dir_bytes + leaf_bytes + waves * per_wave;
+    int blocks_per_cu = lds_cap / lds;
+    if (blocks_per_cu * waves > 32) blocks_per_cu = 32 / waves;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
+    long long grid = (long long)cus * blocks_per_cu;
+    const long long need = (N + waves - 1) / waves;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    g->grid = (int)grid;
+    g->block = waves * kWave;
+    g->lds = lds;
+    g->leaf_in_lds = leaf_bytes > 0;
+    g->Lmax = Lmax;
+    return GENIE_OK;
+}
+
+template <int MODE>
+int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                     int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
+                     int32_t cap, int32_t *d_status, hipStream_t s)
+{
+    auto kern = find_smems_kernel<MODE>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
+                       fixed_len, g.Lmax, min_len, d_counts, reinterpret_cast<int4 *>(d_slots), cap, d_status,
+                       g.leaf_in_lds);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+}  // namespace
+
+void set_hip_error(const char *what, int code)
+{
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = std::string(what) + ": " + hipGetErrorString((hipError_t)code);
+}
+
+const char *last_hip_error()
+{
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return g_err.c_str();
+}
+
+int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
+                        int32_t *lds_bytes)
+{
+    Geometry g;
+    int rc = plan_find_smems(ix, mode, max_len, 1ll << 40, &g);
+    if (rc) return rc;
+    if (grid) *grid = g.grid;
+    if (block) *block = g.block;
+    if (lds_bytes) *lds_bytes = g.lds;
+    return GENIE_OK;
+}
+
+int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                      int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
+                      int32_t cap, int32_t *d_status, void *stream)
+{
+    if (N == 0) return GENIE_OK;
+    Geometry g;
+    // with ragged lengths `fixed_len` carries the maximum length (host contract)
+    int rc = plan_find_smems(ix, mode, fixed_len, N, &g);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+    case GENIE_MODE_BWA:
+        return launch_find_mode<GENIE_MODE_BWA>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
+                                                cap, d_status, s);
+    case GENIE_MODE_LUT:
+        return launch_find_mode<GENIE_MODE_LUT>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
+                                                cap, d_status, s);
+    case GENIE_MODE_RMI:
+        return launch_find_mode<GENIE_MODE_RMI>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
+                                                cap, d_status, s);
+    }
+    return GENIE_E_INVALID;
+}
+
+int launch_sa_interval(const genie_index *ix, const uint8_t *d_pats, const int32_t *d_lens, int64_t N, int32_t stride,
+                       int32_t fixed_len, int32_t *d_out, void *stream)
+{
+    if (N == 0) return GENIE_OK;
+    const DevIndex &d = ix->dev;
+    const int dir_bytes = (d.dir_entries * 4 + 15) & ~15;
+    const int Lmax = std::max(32, (fixed_len + 31) / 32 * 32);
+    const int per_wave = scratch_bytes(Lmax);
+    int waves = (160 * 1024 - dir_bytes) / per_wave;
+    if (waves < 1) return GENIE_E_TOO_LONG;
+    waves = waves >= 4 ? 4 : (waves >= 2 ? 2 : 1);
+    const int lds = dir_bytes + waves * per_wave;
+    const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
+    long long grid = std::min<long long>((N + waves - 1) / waves, (long long)cus * std::max(1, (160 * 1024) / lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sa_interval_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(sa_interval_kernel, dim3((unsigned)grid), dim3(waves * kWave), lds, (hipStream_t)stream, ix->dev,
+                       d_pats, d_lens, (long long)N, stride, fixed_len, Lmax, reinterpret_cast<int2 *>(d_out));
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int launch_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmers, int64_t N, int32_t *d_out,
+                       double *d_pred, void *stream)
+{
+    if (N == 0) return GENIE_OK;
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    if (mode == GENIE_MODE_LUT)
+        hipLaunchKernelGGL(seed_lookup_kernel<GENIE_MODE_LUT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ix->dev,
+                           d_kmers, (long long)N, reinterpret_cast<int2 *>(d_out), d_pred);
+    else if (mode == GENIE_MODE_RMI)
+        hipLaunchKernelGGL(seed_lookup_kernel<GENIE_MODE_RMI>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ix->dev,
+                           d_kmers, (long long)N, reinterpret_cast<int2 *>(d_out), d_pred);
+    else
+        return GENIE_E_INVALID;
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+int64_t compact_tmp_bytes(int64_t N)
+{
+    const int64_t nblocks = (N + kScanBlock - 1) / kScanBlock;
+    return (nblocks + 2) * 8 + 16;
+}
+
+int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap, int64_t *d_offsets,
+                   int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, s));
+        return GENIE_OK;
+    }
+    const long long nblocks = (N + kScanBlock - 1) / kScanBlock;
+    unsigned long long *sums = reinterpret_cast<unsigned long long *>(d_tmp);
+    int *overflow = reinterpret_cast<int *>(sums + nblocks + 1);
+    HIP_TRY(hipMemsetAsync(overflow, 0, 4, s));
+    hipLaunchKernelGGL(compact_block_sums, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_counts, (long long)N, cap, sums);
+    hipLaunchKernelGGL(compact_scan_sums, dim3(1), dim3(kScanBlock), 0, s, sums, nblocks);
+    hipLaunchKernelGGL(compact_scatter, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_counts,
+                       reinterpret_cast<const int4 *>(d_slots), (long long)N, cap, sums,
+                       reinterpret_cast<long long *>(d_offsets), reinterpret_cast<int4 *>(d_out), (long long)out_cap_rows,
+                       overflow);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+}  // namespace genie

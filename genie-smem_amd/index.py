@@ -1,0 +1,246 @@
+"""GenieIndex: the device-resident index (suffix array, 2-bit packed reference, P-mer prefix
+directory, K-mer table, optional RMI) and the batched entry points of the hot path.
+
+Everything that computes goes through the C ABI (include/genie_smem.h); torch only owns the
+device memory, the stream and -- multi-GPU -- the one-time broadcast of the index image.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(device):
+    if device.type != "cuda":
+        raise RuntimeError("the SMEM hot path runs on an MI355X only (no CPU fallback); tensor is on " + str(device))
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class GenieIndex:
+    def __init__(self):
+        self._h = C.c_void_p(0)
+        self.blob = None            # torch uint8 tensor holding the device image (keeps it alive)
+        self._host_blob = None
+        self.device = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.lib().genie_index_destroy(h)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+    # ------------------------------------------------------------------ construction (host)
+    @classmethod
+    def build(cls, codes, K, dir_bits=7, sa_one_based=None):
+        """codes: uint8 array of base codes 0..3; K: LUT / RMI key size (0 = none);
+        sa_one_based: adopt this suffix array (reference JSON convention) instead of building."""
+        codes = np.ascontiguousarray(codes, np.uint8)
+        self = cls()
+        u8p = C.POINTER(C.c_uint8)
+        if sa_one_based is None:
+            rc = N.lib().genie_index_create(codes.ctypes.data_as(u8p), codes.size, int(K), int(dir_bits),
+                                            C.byref(self._h))
+        else:
+            sa = np.ascontiguousarray(sa_one_based, np.int32)
+            if sa.size != codes.size + 1:
+                raise ValueError("suffix array must have n+1 rows")
+            rc = N.lib().genie_index_create_from_sa(codes.ctypes.data_as(u8p), codes.size,
+                                                    sa.ctypes.data_as(C.POINTER(C.c_int32)), int(K), int(dir_bits),
+                                                    C.byref(self._h))
+        N.check(rc, "genie_index_create")
+        return self
+
+    def set_rmi(self, experts, coefs, icpts):
+        """experts: the reference's list (RMI.experts); coefs/icpts: per-level float64 arrays."""
+        sizes = np.asarray([len(c) for c in coefs], np.int32)
+        scales = np.asarray(list(experts) + [1], np.int32)
+        if len(sizes) != len(scales):
+            raise ValueError("need len(experts)+1 levels of coefficients")
+        coef = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64) for c in coefs]))
+        icpt = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64) for c in icpts]))
+        i32p, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        N.check(N.lib().genie_index_set_rmi(self._h, len(sizes), sizes.ctypes.data_as(i32p),
+                                            scales.ctypes.data_as(i32p), coef.ctypes.data_as(dp),
+                                            icpt.ctypes.data_as(dp)), "genie_index_set_rmi")
+        self._host_blob = None
+
+    def info(self):
+        inf = N.GenieInfo()
+        N.check(N.lib().genie_index_info(self._h, C.byref(inf)), "genie_index_info")
+        return {f: getattr(inf, f) for f, _ in N.GenieInfo._fields_}
+
+    @property
+    def n(self):
+        return self.info()["n"]
+
+    @property
+    def K(self):
+        return self.info()["K"]
+
+    def suffix_array(self):
+        """1-based suffix array as the reference stores it (row 0 = n+1); host copy."""
+        p = N.lib().genie_index_suffix_array(self._h)
+        if not p:
+            raise RuntimeError("this handle has no host arrays (opened from a broadcast image)")
+        return np.ctypeslib.as_array(p, (self.n + 1,))
+
+    def lut_arrays(self):
+        """Sorted distinct K-mer codes and their inclusive SA intervals (host views)."""
+        cp, lp, hp = C.POINTER(C.c_uint32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        N.check(N.lib().genie_index_lut_arrays(self._h, C.byref(cp), C.byref(lp), C.byref(hp)), "genie_index_lut_arrays")
+        m = self.info()["lut_keys"]
+        if m == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.int32), np.zeros(0, np.int32)
+        return (np.ctypeslib.as_array(cp, (m,)), np.ctypeslib.as_array(lp, (m,)), np.ctypeslib.as_array(hp, (m,)))
+
+    # ------------------------------------------------------------------ image / device
+    def serialize(self):
+        """The flat index image as a CPU uint8 tensor (header + sections)."""
+        if self._host_blob is None:
+            nbytes = N.lib().genie_index_blob_bytes(self._h)
+            if nbytes <= 0:
+                raise N.GenieError(int(nbytes), "genie_index_blob_bytes")
+            buf = torch.empty(nbytes, dtype=torch.uint8)
+            N.check(N.lib().genie_index_serialize(self._h, C.c_void_p(buf.data_ptr()), nbytes), "genie_index_serialize")
+            self._host_blob = buf
+        return self._host_blob
+
+    def to(self, device):
+        """Upload the image with torch and bind it (torch owns the device memory)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("GenieIndex.to: an MI355X device is required (no CPU fallback)")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        host = self.serialize()
+        self._bind(host.to(device), host[:N.HEADER_BYTES])
+        return self
+
+    def _bind(self, dev_blob, host_header):
+        host_header = host_header.contiguous()
+        dev_index = dev_blob.device.index if dev_blob.device.type == "cuda" else -1
+        N.check(N.lib().genie_index_open(C.c_void_p(host_header.data_ptr()), C.c_void_p(dev_blob.data_ptr()),
+                                         dev_blob.numel(), dev_index, C.byref(self._h)), "genie_index_open")
+        self.blob = dev_blob
+        self.device = dev_blob.device
+
+    @classmethod
+    def from_image(cls, dev_blob):
+        """Open an image that already sits in device memory (e.g. received by broadcast)."""
+        self = cls()
+        self._bind(dev_blob, dev_blob[:N.HEADER_BYTES].cpu())
+        return self
+
+    # ------------------------------------------------------------------ hot path
+    def _need_device(self):
+        if self.blob is None or self.device is None or self.device.type != "cuda":
+            raise RuntimeError("index is not on a GPU: call GenieIndex.to('cuda') first (no CPU fallback)")
+
+    def _as_dev(self, t, dtype):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.ascontiguousarray(t))
+        t = t.to(device=self.device, dtype=dtype)
+        return t.contiguous()
+
+    def sa_interval(self, pats, lens=None):
+        """Batched exact_match_back_prop.  pats: [N, stride] uint8 codes; lens: [N] or None.
+        Returns int32 [N, 2] (lo, hi); (-1,-1) absent; (-2,-2) code > 3."""
+        self._need_device()
+        pats = self._as_dev(pats, torch.uint8)
+        if pats.dim() != 2:
+            raise ValueError("pats must be [N, stride]")
+        n_pat, stride = pats.shape
+        fixed = stride
+        if lens is not None:
+            lens = self._as_dev(lens, torch.int32)
+            fixed = int(lens.max().item()) if n_pat else 0
+            if fixed > stride or (n_pat and int(lens.min().item()) < 0):
+                raise ValueError("pattern length outside [0, stride]")
+        if stride == 0:
+            pats = torch.zeros((n_pat, 1), dtype=torch.uint8, device=self.device)
+            stride = 1
+        out = torch.empty((n_pat, 2), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().genie_sa_interval(self._h, _ptr(pats), _ptr(lens), n_pat, stride, fixed, _ptr(out),
+                                              _stream(self.device)), "genie_sa_interval")
+        return out
+
+    def seed_lookup(self, mode, kmers, want_pred=False):
+        """Batched K-mer seed lookup (LUT membership / RMI get_suffix_rmi). kmers: [N, K] codes."""
+        self._need_device()
+        kmers = self._as_dev(kmers, torch.uint8)
+        if kmers.dim() != 2 or kmers.shape[1] != self.K:
+            raise ValueError("kmers must be [N, K]")
+        out = torch.empty((kmers.shape[0], 2), dtype=torch.int32, device=self.device)
+        pred = torch.empty(kmers.shape[0], dtype=torch.float64, device=self.device) if want_pred else None
+        with torch.cuda.device(self.device):
+            N.check(N.lib().genie_seed_lookup(self._h, N.MODES[mode], _ptr(kmers), kmers.shape[0], _ptr(out),
+                                              _ptr(pred), _stream(self.device)), "genie_seed_lookup")
+        return (out, pred) if want_pred else out
+
+    def find_smems_slots(self, mode, reads, lens=None, min_len=1, cap=None):
+        """One launch of the SMEM kernel.  reads: [N, stride] uint8 codes on the device.
+        Returns (counts int32[N], slots int32[N, cap, 4], status int32[N])."""
+        self._need_device()
+        reads = self._as_dev(reads, torch.uint8)
+        if reads.dim() != 2:
+            raise ValueError("reads must be [N, stride]")
+        n_reads, stride = reads.shape
+        fixed = stride
+        if lens is not None:
+            lens = self._as_dev(lens, torch.int32)
+            fixed = int(lens.max().item()) if n_reads else 0
+            if fixed > stride or (n_reads and int(lens.min().item()) < 0):
+                raise ValueError("read length outside [0, stride]")
+        if cap is None:
+            cap = max(1, fixed)
+        counts = torch.empty(n_reads, dtype=torch.int32, device=self.device)
+        slots = torch.empty((n_reads, cap, 4), dtype=torch.int32, device=self.device)
+        status = torch.empty(n_reads, dtype=torch.int32, device=self.device)
+        if n_reads == 0 or stride == 0:
+            counts.zero_()
+            status.zero_()
+            return counts, slots, status
+        with torch.cuda.device(self.device):
+            N.check(N.lib().genie_find_smems(self._h, N.MODES[mode], _ptr(reads), _ptr(lens), n_reads, stride, fixed,
+                                             int(min_len), _ptr(counts), _ptr(slots), cap, _ptr(status),
+                                             _stream(self.device)), "genie_find_smems")
+        return counts, slots, status
+
+    def compact(self, counts, slots, out=None):
+        """Slotted output -> CSR: (offsets int64[N+1], smems int32[S, 4])."""
+        self._need_device()
+        n_reads, cap = slots.shape[0], slots.shape[1]
+        offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=self.device)
+        tmp = torch.empty(max(int(N.lib().genie_compact_tmp_bytes(n_reads)), 16), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            st = _stream(self.device)
+            if out is None:
+                N.check(N.lib().genie_compact_smems(_ptr(counts), _ptr(slots), n_reads, cap, _ptr(offsets),
+                                                    C.c_void_p(0), 0, _ptr(tmp), st), "genie_compact_smems")
+                total = int(offsets[-1].item())
+                out = torch.empty((max(total, 1), 4), dtype=torch.int32, device=self.device)
+            N.check(N.lib().genie_compact_smems(_ptr(counts), _ptr(slots), n_reads, cap, _ptr(offsets), _ptr(out),
+                                                out.shape[0], _ptr(tmp), st), "genie_compact_smems")
+        return offsets, out
+
+    def find_smems(self, mode, reads, lens=None, min_len=1, cap=None):
+        """Batched SMEM discovery -> (offsets int64[N+1], smems int32[S,4] = (start,end,lo,hi), status)."""
+        counts, slots, status = self.find_smems_slots(mode, reads, lens, min_len, cap)
+        offsets, out = self.compact(counts, slots)
+        total = int(offsets[-1].item())
+        return offsets, out[:total], status
+
+    def launch_info(self, mode, max_len):
+        g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
+        N.check(N.lib().genie_launch_info(self._h, N.MODES[mode], int(max_len), C.byref(g), C.byref(b), C.byref(l)),
+                "genie_launch_info")
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value}

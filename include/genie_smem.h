@@ -1,0 +1,184 @@
+/*
+ * genie_smem.h -- C ABI of the MI355X-native batched SMEM finder (libgenie_smem.so).
+ *
+ * This is the drop-in boundary for the one hot path of jgkellymit/GENIE-SMEM: seed lookup,
+ * suffix-array interval search and the SMEM extension loop.  The reference has no FFI (it is
+ * in-process Python), so each entry point names the reference method it replaces; the Python
+ * classes in genie-smem_amd/ bind these with ctypes and re-expose the reference's own method
+ * names (see INTEGRATION.md for the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in any signature (`stream` is a
+ *     hipStream_t passed as void*, 0 = the null stream);
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch tensors);
+ *     everything else is host memory;
+ *   - bases are codes 0..3 in the sorted order of the reference alphabet (ACGT -> 0..3, the
+ *     map of LUT.convert_seq_to_num, reference SMEM/LUT.py:37-48);
+ *   - suffix-array rows: n+1 rows, row 0 is the '$' suffix; intervals are 0-based inclusive
+ *     [lo, hi] exactly as ExactMatch.exact_match_back_prop returns them (SMEM/ExactMatch.py:151);
+ *     an absent pattern is (-1, -1) where the reference returns the int -1;
+ *   - every function returns 0 (GENIE_OK) or a negative genie_status; none throws.
+ *   - an index handle is immutable once opened on a device: any number of concurrent calls on
+ *     distinct streams may share it.
+ */
+#ifndef GENIE_SMEM_H
+#define GENIE_SMEM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENIE_ABI_VERSION 1
+#define GENIE_HEADER_BYTES 512      /* fixed-size header at the start of a serialized index */
+#define GENIE_MAX_K 16              /* K-mer codes are 32-bit (2 bits per base) */
+#define GENIE_MAX_DIR_BITS 7        /* P: prefix directory has 4^P + 1 entries, staged in LDS */
+#define GENIE_MAX_READ_LEN 8192     /* per-read scratch lives in LDS */
+#define GENIE_MAX_RMI_LEVELS 4
+
+typedef enum genie_status {
+    GENIE_OK = 0,
+    GENIE_E_INVALID = -1,      /* bad argument (null pointer, negative size, K out of range ...) */
+    GENIE_E_ALPHABET = -2,     /* a base code > 3 in the reference */
+    GENIE_E_NOMEM = -3,
+    GENIE_E_NO_DEVICE = -4,    /* index has no device image (call genie_index_open / _to_device) */
+    GENIE_E_HIP = -5,          /* HIP runtime error; see genie_last_hip_error() */
+    GENIE_E_TOO_LONG = -6,     /* read/pattern longer than GENIE_MAX_READ_LEN */
+    GENIE_E_NO_MODEL = -7,     /* RMI mode requested but no model was set */
+    GENIE_E_BAD_BLOB = -8,     /* serialized index: wrong magic / version / size */
+    GENIE_E_NO_LUT = -9,       /* LUT mode requested but the index was built with K = 0 */
+    GENIE_E_CAPACITY = -10     /* output buffer too small (compaction) */
+} genie_status;
+
+/* Per-read status written by genie_find_smems into d_status (0 = ok).  They mirror how the
+ * reference fails on the same input (SURVEY.md section 8a "quirks"). */
+enum {
+    GENIE_READ_OK = 0,
+    GENIE_READ_BAD_BASE = 1,   /* code > 3: reference raises KeyError (ExactMatch.py:139, LUT.py:47) */
+    GENIE_READ_TOO_SHORT = 2,  /* len < K in LUT/RMI mode: reference mis-encodes (SMEM.py:26-28) */
+    GENIE_READ_ABSENT_BASE = 3,/* a base that never occurs in the reference: reference raises
+                                  KeyError('') (SMEM.py:39) or never terminates (SMEM.py:465,484) */
+    GENIE_READ_OVERFLOW = 4    /* more SMEMs than `cap` slots; d_counts holds the true count */
+};
+
+/* SMEM traversal selector == which reference method is replaced. */
+enum {
+    GENIE_MODE_BWA = 0,        /* SMEM.get_SMEMS        (SMEM/SMEM.py:456-467) */
+    GENIE_MODE_LUT = 1,        /* SMEM.get_smems_lut    (SMEM/SMEM.py:20-192)  */
+    GENIE_MODE_RMI = 2         /* SMEM.get_smems_rmi    (SMEM/SMEM.py:206-384) */
+};
+
+typedef struct genie_index genie_index;
+
+typedef struct genie_info {
+    int64_t n;                 /* reference length in bases (without '$') */
+    int32_t K;                 /* LUT / RMI key size (lut_size, prediction_size); 0 = none */
+    int32_t dir_bits;          /* P */
+    int64_t lut_keys;          /* distinct K-mers (len(lut.lut) in the reference) */
+    int64_t lut_slots;         /* device hash-table slots */
+    int32_t rmi_levels;        /* 0 = no model */
+    int32_t has_host;          /* host arrays present (built here, not attached from a blob) */
+    int32_t has_device;        /* device image bound */
+    int32_t device;            /* HIP device ordinal of the image, -1 if none */
+    int64_t blob_bytes;        /* size of the serialized / device image */
+} genie_info;
+
+/* ---------------------------------------------------------------------------------------
+ * Index construction (host).  Replaces ExactMatch.create_fm_index + LUT.generate_lut
+ * (SMEM/ExactMatch.py:22-33, SMEM/LUT.py:15-35): builds the suffix array of ref+"$", the
+ * 2-bit packed reference, the P-mer prefix directory and (K > 0) the K-mer table.
+ * No FM Occ/BWT is built: suffix-array bound search gives the same intervals (tests pin this).
+ * ------------------------------------------------------------------------------------- */
+int genie_index_create(const uint8_t *codes, int64_t n, int32_t K, int32_t dir_bits, genie_index **out);
+
+/* Same, but adopt a suffix array supplied by the caller in the reference's JSON convention
+ * (fm_index["suffix_array"]: n+1 entries, 1-based starts, row 0 = n+1; SMEM/ExactMatch.py:66).
+ * Used by ExactMatch.load_fm_index on files the reference wrote. */
+int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K,
+                               int32_t dir_bits, genie_index **out);
+
+/* Install an RMI model (RMI.models after RMI.fit, SMEM/RMI.py:10-50): `nlev` levels, level l has
+ * sizes[l] linear models (sizes[0] == 1) and the clamp scale scales[l] (= experts + [1], RMI.py:54);
+ * coef / icpt are the per-level arrays concatenated.  Must precede serialize / to_device. */
+int genie_index_set_rmi(genie_index *ix, int32_t nlev, const int32_t *sizes, const int32_t *scales,
+                        const double *coef, const double *icpt);
+
+int genie_index_info(const genie_index *ix, genie_info *out);
+
+/* Host views for the position-resolution helpers of the drop-in API
+ * (ExactMatch.get_position(s) / exact_match, SMEM/ExactMatch.py:174-199).
+ * 1-based values as the reference stores them; NULL when the handle has no host arrays. */
+const int32_t *genie_index_suffix_array(const genie_index *ix);
+/* Sorted distinct K-mer table (the reference's lut dict in key order): codes/lo/hi[lut_keys]. */
+int genie_index_lut_arrays(const genie_index *ix, const uint32_t **codes, const int32_t **lo, const int32_t **hi);
+
+/* Serialize to one flat, position-independent image (header + sections).  The caller uploads
+ * it (e.g. torch.from_numpy(buf).cuda()) and -- multi-GPU -- broadcasts that ONE tensor over
+ * RCCL; every rank then calls genie_index_open on its copy. */
+int64_t genie_index_blob_bytes(const genie_index *ix);
+int genie_index_serialize(const genie_index *ix, void *host_dst, int64_t cap);
+
+/* Open a device-resident image.  `host_header` = the first GENIE_HEADER_BYTES of the same
+ * image in host memory (ranks that received it by broadcast copy those bytes back).  The
+ * image is NOT copied and must outlive the handle.  If `ix_inout` points at an existing handle
+ * the image is bound to it (keeps the host arrays); otherwise a device-only handle is made. */
+int genie_index_open(const void *host_header, const void *d_blob, int64_t blob_bytes, int32_t device,
+                     genie_index **ix_inout);
+
+/* Convenience for non-torch callers: hipMalloc + upload an image owned by the handle. */
+int genie_index_to_device(genie_index *ix, int32_t device);
+
+void genie_index_destroy(genie_index *ix);
+
+/* ---------------------------------------------------------------------------------------
+ * Hot path (device).  All launches are asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------- */
+
+/* Batched ExactMatch.exact_match_back_prop (SMEM/ExactMatch.py:132-151):
+ * pattern i = d_pats[i*stride .. +len_i) with len_i = d_lens ? d_lens[i] : fixed_len;
+ * d_out_lohi[2i..2i+1] = inclusive SA interval, or (-1,-1) if absent; an empty pattern gives
+ * (0, n) like the reference; a code > 3 gives (-2,-2) (reference: KeyError). */
+int genie_sa_interval(const genie_index *ix, const uint8_t *d_pats, const int32_t *d_lens, int64_t N,
+                      int32_t stride, int32_t fixed_len, int32_t *d_out_lohi, void *stream);
+
+/* Batched seed lookup of one K-mer each (N rows of K codes, row stride K):
+ * mode LUT: `lut[str(code)][0]` membership + interval (SMEM/SMEM.py:28-32,65-67);
+ * mode RMI: RMI_LUT.get_suffix_rmi = predict + last-mile search (SMEM/RMI_LUT.py:67-184),
+ * contract behaviour = the true interval; an absent K-mer is reported the reference's way,
+ * lower > upper (lower = the row it would be inserted at).  LUT output as genie_sa_interval.
+ * d_pred (may be NULL,
+ * RMI only) receives the float64 prediction of RMI_LUT.rmi_predict (SMEM/RMI_LUT.py:53-63). */
+int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmers, int64_t N,
+                      int32_t *d_out_lohi, double *d_pred, void *stream);
+
+/* Batched SMEM discovery: replaces SMEM.get_SMEMS / get_smems_lut / get_smems_rmi.
+ * Read r = d_reads[r*stride .. +len_r), len_r = d_lens ? d_lens[r] : fixed_len.
+ * Writes d_counts[r] = number of SMEMs of read r (after the min_len filter, which the
+ * reference applies in BWA mode only, SMEM.py:463; pass 1 otherwise) and
+ * d_slots[(r*cap + t)*4 + {0,1,2,3}] = (start, end, lo, hi) of its t-th SMEM in the
+ * reference's emission order: the substring read[start:end) and its SA interval [lo, hi].
+ * d_status[r] (may be NULL) = GENIE_READ_* code.  `cap` slots per read (cap >= max read
+ * length never overflows). */
+int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
+                     int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
+                     int32_t *d_slots, int32_t cap, int32_t *d_status, void *stream);
+
+/* Compact the slotted output to CSR: d_offsets[N+1] (exclusive prefix sum of min(count,cap))
+ * and d_out[total*4].  d_tmp: scratch of genie_compact_tmp_bytes(N) bytes. */
+int64_t genie_compact_tmp_bytes(int64_t N);
+int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap,
+                        int64_t *d_offsets, int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
+
+/* Launch geometry actually used by genie_find_smems for (mode, max read length): for reports. */
+int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
+                      int32_t *lds_bytes);
+
+const char *genie_strerror(int status);
+const char *genie_last_hip_error(void);
+int genie_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENIE_SMEM_H */

@@ -1,0 +1,321 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against (a) the golden vectors produced by the unmodified reference and (b) the CPU oracle on
+fresh seeded inputs.  Integer work: every comparison is bit-exact.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import genie_smem_amd as g
+    g._native.lib()
+    return g
+
+
+_IX = {}
+
+
+def _index(pkg, ds, with_rmi=None):
+    """GenieIndex for a golden dataset (optionally with the fixture's RMI coefficients)."""
+    key = (ds, with_rmi)
+    if key not in _IX:
+        d, _ = G.load(ds)
+        ix = pkg.GenieIndex.build(d["ref_codes"], int(d["K"]))
+        if with_rmi is not None:
+            ex = [int(x) for x in d[f"{with_rmi}.experts"]]
+            ix.set_rmi(ex, [d[f"{with_rmi}.coef{l}"] for l in range(len(ex) + 1)],
+                       [d[f"{with_rmi}.icpt{l}"] for l in range(len(ex) + 1)])
+        _IX[key] = ix.to("cuda")
+    return _IX[key]
+
+
+def _rmi_tag(ds):
+    d, _ = G.load(ds)
+    tag = "g4_" + "_".join(str(int(x)) for x in d["experts"])
+    return tag if f"{tag}.coef0" in d else None
+
+
+def _index_for(pkg, ds, algo):
+    if algo != "rmi":
+        return _index(pkg, ds)
+    tag = _rmi_tag(ds)
+    if tag:
+        return _index(pkg, ds, tag)
+    key = (ds, "trained")
+    if key not in _IX:                       # no reference coefficients in the fixture: fit our own
+        d, _ = G.load(ds)
+        m = pkg.ExactMatch(ds + ".fa")
+        m.set_reference(G.codes_to_str(d["ref_codes"]))
+        r = pkg.RMI_LUT([int(x) for x in d["experts"]], int(d["K"]), ds + ".fa", matcher=m)
+        r.train_RMI()
+        _IX[key] = r._index()
+    return _IX[key]
+
+
+def _rows_per_read(offsets, smems):
+    off = offsets.cpu().numpy()
+    sm = smems.cpu().numpy()
+    return [sm[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+# ------------------------------------------------------------------ A1: exact_match_back_prop
+@pytest.mark.parametrize("ds", [d for d in G.DATASETS if G.have(d)])
+def test_sa_interval_golden(pkg, ds):
+    d, _ = G.load(ds)
+    ix = _index(pkg, ds)
+    off, pat, want = d["g5.pat_off"], d["g5.pat"], d["g5.lohi"]
+    lens = np.diff(off).astype(np.int32)
+    mat = np.zeros((len(lens), int(lens.max())), np.uint8)
+    for i in range(len(lens)):
+        mat[i, :lens[i]] = pat[off[i]:off[i + 1]]
+    got = ix.sa_interval(mat, lens).cpu().numpy()
+    assert (got == want).all(), np.nonzero((got != want).any(1))[0][:10]
+
+
+def test_sa_interval_edges(pkg):
+    ix = _index(pkg, "medium_K6")
+    n = ix.n
+    mat = np.zeros((3, 4), np.uint8)
+    mat[1] = [0, 1, 7, 0]
+    got = ix.sa_interval(mat, np.asarray([0, 4, 1], np.int32)).cpu().numpy()
+    assert got[0].tolist() == [0, n]                    # "" -> (0, n) like the reference
+    assert got[1].tolist() == [-2, -2]                  # code > 3 (reference: KeyError)
+    assert got[2, 0] >= 1
+
+
+def test_dropin_exact_match_mississippi(pkg):
+    k = G.known()["mississippi"]
+    m = pkg.ExactMatch("mississippi.fa")
+    m.set_reference(k["ref"])
+    for q, want in k["back_prop"].items():
+        got = m.exact_match_back_prop(q)
+        assert got == (-1 if want == -1 else tuple(want)), q
+    for q, pos in k["exact_match"].items():
+        assert m.exact_match(q) == pos
+    with pytest.raises(KeyError):
+        m.exact_match_back_prop("mixs")                 # 'x' not in count_dic (ExactMatch.py:139)
+    with pytest.raises(TypeError):
+        m.exact_match("mm")                             # reference unpacks -1 (ExactMatch.py:181)
+    # one backward-search step == searching the longer string
+    iv = m.exact_match_back_prop("ssi")
+    assert m.exact_match_back_prop_add_one("i", iv) == m.exact_match_back_prop("issi")
+    assert m.exact_match_back_prop_add_one("p", iv) == -1
+    assert m.get_positions(*m.exact_match_back_prop("ssi")) == [6, 3] and m.get_position(0) == 12
+
+
+# ------------------------------------------------------------------ A2 / A5 / A9: traversals vs goldens
+@pytest.mark.parametrize("ds,tag,algo", G.group_cases())
+def test_traversal_golden(pkg, ds, tag, algo):
+    ix = _index_for(pkg, ds, algo)
+    rd = G.reads(ds, tag)
+    items = G.ref_items(ds, tag, algo)
+    trace = G.ref_trace(ds, tag, algo)
+    status = G.ref_status(ds, tag, algo)
+    lut_items = G.ref_items(ds, tag, "lut") if algo == "rmi" else None
+    offsets, smems, st = ix.find_smems(algo, rd[:len(status)], min_len=1)
+    assert (st.cpu().numpy() == 0).all()
+    rows = _rows_per_read(offsets, smems)
+    checked = 0
+    for r in range(len(status)):
+        if algo == "rmi":
+            assert G.dict_view(rd[r], rows[r]) == lut_items[r], r      # always-on gate
+            if status[r] != 0 or items[r] != lut_items[r]:
+                continue                                               # tagged reference defect
+        assert G.dict_view(rd[r], rows[r]) == items[r], r
+        if algo == "bwa":
+            assert rows[r].tolist() == trace[r].tolist(), r
+        else:
+            assert rows[r][:, :2].tolist() == trace[r][:len(rows[r])].tolist(), r
+        checked += 1
+    assert checked >= (len(status) * 3) // 4
+
+
+def test_dropin_smem_api(pkg):
+    k = G.known()
+    m = pkg.ExactMatch("mississippi.fa")
+    m.set_reference(k["mississippi"]["ref"])
+    s = pkg.SMEM(m, lut_size=3)
+    for q, want in k["mississippi"]["get_SMEMS"].items():
+        assert [(a, b[0], b[1]) for a, b in s.get_SMEMS(q, 1).items()] == [tuple(w) for w in want], q
+    for q, want in k["mississippi"]["get_SMEMS_min3"].items():
+        assert [(a, b[0], b[1]) for a, b in s.get_SMEMS(q, 3).items()] == [tuple(w) for w in want], q
+    with pytest.raises(KeyError):
+        s.get_SMEMS("aaaaa", 1)                           # aaaaa -> KeyError('a')
+    # single-step helpers keep the reference's shapes
+    assert s.get_SMEM_at_index("pissssi", 1) == ["iss", (3, 4), 4]
+    fm, longest = s.forward_extension("missippi", 0)
+    assert longest == "missi" and list(fm) == ["m", "mi", "mis", "miss", "missi"]
+    assert s.check_sequential([5, 2], [6, 3]) and not s.check_sequential([5], [7])
+
+    m2 = pkg.ExactMatch("paperex.fa")
+    m2.set_reference(k["paperex"]["ref"])
+    s2 = pkg.SMEM(m2, lut_size=2)
+    assert {kk: [list(v[0]), v[1]] for kk, v in s2.lut.lut.items()} == k["paperex"]["lut"]
+    for q, want in k["paperex"]["get_SMEMS"].items():
+        assert [(a, b[0], b[1]) for a, b in s2.get_SMEMS(q, 1).items()] == [tuple(w) for w in want], q
+    for q, want in k["paperex"]["get_smems_lut"].items():
+        assert [(a, b[0], b[1]) for a, b in s2.get_smems_lut(q).items()] == [tuple(w) for w in want], q
+    with pytest.raises(ValueError):
+        s2.get_smems_lut("A")                             # shorter than K
+
+
+# ------------------------------------------------------------------ A6 / A8: seeds
+def test_lut_seed_lookup(pkg):
+    ds = "syn100k_K15"
+    d, _ = G.load(ds)
+    ix = _index(pkg, ds)
+    K = int(d["K"])
+    codes, lo, hi = ix.lut_arrays()
+    sel = np.random.default_rng(5).choice(len(codes), 20000, replace=False)
+    kmers = ((codes[sel, None].astype(np.int64) >> (2 * (K - 1 - np.arange(K)))) & 3).astype(np.uint8)
+    got = ix.seed_lookup("lut", kmers).cpu().numpy()
+    assert (got[:, 0] == lo[sel]).all() and (got[:, 1] == hi[sel]).all()
+    absent = np.random.default_rng(6).integers(0, 4, (20000, K)).astype(np.uint8)
+    got = ix.seed_lookup("lut", absent).cpu().numpy()
+    w = 4 ** np.arange(K - 1, -1, -1, dtype=np.int64)
+    present = np.isin((absent.astype(np.int64) * w).sum(1), codes.astype(np.int64))
+    assert ((got[:, 0] >= 0) == present).all()
+
+
+@pytest.mark.parametrize("ds", [d for d in ("syn100k_K15", "big100k_K15") if G.have(d)])
+def test_rmi_predict_bit_exact_and_true_interval(pkg, ds):
+    d, _ = G.load(ds)
+    for tag in sorted({k.split(".")[0] for k in d if k.startswith("g4_")}):
+        ix = _index(pkg, ds, tag)
+        lohi, pred = ix.seed_lookup("rmi", d[f"{tag}.kmers"], want_pred=True)
+        lohi, pred = lohi.cpu().numpy(), pred.cpu().numpy()
+        assert (pred == d[f"{tag}.pred"]).all(), tag                 # float64, bit for bit
+        truth = d[f"{tag}.truth"]
+        absent = truth[:, 0] < 0
+        assert (lohi[~absent] == truth[~absent]).all(), tag
+        assert (lohi[absent, 0] > lohi[absent, 1]).all(), tag        # reference convention lower > upper
+        # the reference itself agrees wherever it is not tagged as defective
+        ok = d[f"{tag}.defect"] == 0
+        ref = d[f"{tag}.lohi"]
+        assert (lohi[ok & ~absent] == ref[ok & ~absent]).all()
+
+
+def test_dropin_rmi_lut(pkg):
+    d, _ = G.load("syn10k_K8")
+    m = pkg.ExactMatch("syn10k.fa")
+    m.set_reference(G.codes_to_str(d["ref_codes"]))
+    r = pkg.RMI_LUT([10, 100], 8, "syn10k.fa", matcher=m)
+    r.train_RMI()
+    q = G.codes_to_str(d["ref_codes"][500:508])
+    assert r.get_suffix_rmi(q) == m.exact_match_back_prop(q)
+    lo, hi = r.get_suffix_rmi("ACGTACGT" if m.exact_match_back_prop("ACGTACGT") == -1 else "TTTTTTTT")
+    s = pkg.SMEM(m, lut_size=8)
+    s.rmi_lut = r
+    rd = G.reads("syn10k_K8", "fromref150")[:20]
+    for row in rd:
+        q = G.codes_to_str(row)
+        assert s.get_smems_rmi(q) == s.get_smems_lut(q) == s.get_SMEMS(q, 1)
+
+
+# ------------------------------------------------------------------ vs the CPU oracle on fresh inputs
+@pytest.mark.parametrize("algo", ["bwa", "lut", "rmi"])
+@pytest.mark.parametrize("ds,L,kind", [("syn100k_K15", 150, "fromref"), ("syn100k_K15", 150, "random"),
+                                       ("big100k_K15", 150, "fromref"), ("syn10k_K8", 97, "fromref"),
+                                       ("medium_K6", 64, "random"), ("syn100k_K15", 777, "fromref")])
+def test_vs_oracle_fresh_reads(pkg, oracle_mod, ds, L, kind, algo):
+    from genie_smem_amd import synth as B
+    d, _ = G.load(ds)
+    ix = _index_for(pkg, ds, algo)
+    o = oracle_mod.Oracle(d["ref_codes"], int(d["K"]))
+    if algo == "rmi":
+        o.set_rmi([], [np.asarray([o.n / 4.0 ** o.K])], [np.asarray([0.0])])   # true-interval contract: any model
+    n_reads = 4000 if L <= 150 else 300
+    rd = B.reads_from_ref(d["ref_codes"], n_reads, L, 4242) if kind == "fromref" else B.reads_random(n_reads, L, 4243)
+    offsets, smems, st = ix.find_smems(algo, rd)
+    assert (st.cpu().numpy() == 0).all()
+    rows = _rows_per_read(offsets, smems)
+    counts, out = o.find_smems_batch(algo, rd, nthreads=8)
+    assert (counts >= 0).all()
+    for r in range(n_reads):
+        assert rows[r].tolist() == out[r, :counts[r]].tolist(), r
+
+
+def test_ragged_and_status(pkg, oracle_mod):
+    d, _ = G.load("syn10k_K8")
+    ix = _index(pkg, "syn10k_K8")
+    o = oracle_mod.Oracle(d["ref_codes"], 8)
+    from genie_smem_amd import synth as B
+    rd = B.reads_from_ref(d["ref_codes"], 64, 120, 99)
+    lens = np.random.default_rng(3).integers(0, 121, 64).astype(np.int32)
+    lens[:4] = [0, 1, 7, 8]
+    rd[5, 3] = 9                                                    # bad base inside the read
+    lens[5] = 50
+    for algo in ("bwa", "lut"):
+        offsets, smems, st = ix.find_smems(algo, rd, lens=lens)
+        st = st.cpu().numpy()
+        rows = _rows_per_read(offsets, smems)
+        for r in range(64):
+            if r == 5:
+                assert st[r] == pkg._native.READ_BAD_BASE and len(rows[r]) == 0
+                continue
+            n, want = o.find_smems(algo, rd[r, :lens[r]])
+            if algo == "lut" and lens[r] < 8:
+                assert st[r] == pkg._native.READ_TOO_SHORT and n == -3 and len(rows[r]) == 0
+            else:
+                assert st[r] == 0 and rows[r].tolist() == want.tolist(), (algo, r)
+    # overflow: cap smaller than the SMEM count keeps the true count and flags the read
+    counts, slots, st = ix.find_smems_slots("bwa", rd[8:9], cap=2)
+    n, want = o.find_smems("bwa", rd[8])
+    assert counts.item() == n and st.item() == pkg._native.READ_OVERFLOW
+    assert slots.cpu().numpy()[0].tolist() == want[:2].tolist()
+
+
+def test_absent_base_is_flagged(pkg):
+    m = pkg.ExactMatch("x.fa")
+    m.set_reference("ACACACCACAACCA")                              # no G, no T
+    ix = m.index(2)
+    rd = np.asarray([[0, 1, 0, 2, 0, 1]], np.uint8)                 # contains G
+    for algo in ("bwa", "lut"):
+        _, _, st = ix.find_smems(algo, rd)
+        assert st.item() == pkg._native.READ_ABSENT_BASE
+    with pytest.raises(KeyError):
+        pkg.SMEM(m, lut_size=2).get_SMEMS("ACAGAC", 1)
+
+
+# ------------------------------------------------------------------ full-size properties (config 2/3 shape)
+def test_full_size_properties(pkg):
+    """1M x 150 bp reads on the 100 kb reference: size-independent properties -- the three
+    traversals agree, every SMEM re-searches to its own interval, covers are monotone."""
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ix = _index_for(pkg, "syn100k_K15", "rmi")
+    n_reads = 1_000_000
+    rd = torch.as_tensor(B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, 1002)).cuda()
+    res = {}
+    for algo in ("bwa", "lut", "rmi"):
+        offsets, smems, st = ix.find_smems(algo, rd)
+        assert int(st.abs().sum().item()) == 0
+        res[algo] = (offsets, smems)
+    assert torch.equal(res["bwa"][0], res["lut"][0]) and torch.equal(res["bwa"][1], res["lut"][1])
+    assert torch.equal(res["rmi"][0], res["lut"][0]) and torch.equal(res["rmi"][1], res["lut"][1])
+    offsets, smems = res["lut"]
+    start, end, lo, hi = smems[:, 0], smems[:, 1], smems[:, 2], smems[:, 3]
+    assert bool(((start >= 0) & (start < end) & (end <= 150) & (lo >= 0) & (lo <= hi) & (hi <= ix.n)).all())
+    # last SMEM of each read ends at the read end; ends strictly increase inside a read
+    last = offsets[1:] - 1
+    assert bool((end[last] == 150).all())
+    same_read = torch.ones(len(end) - 1, dtype=torch.bool, device=end.device)
+    same_read[(offsets[1:-1] - 1)] = False
+    assert bool((end[1:][same_read] > end[:-1][same_read]).all())
+    # re-search a sample of emitted substrings with the batched exact-match kernel
+    sel = torch.randperm(len(start), device=start.device)[:200000]
+    read_of = torch.searchsorted(offsets, sel, right=True) - 1
+    lens = (end[sel] - start[sel]).to(torch.int32)
+    idx = start[sel].long()[:, None] + torch.arange(150, device=rd.device)[None, :]
+    pats = torch.gather(rd[read_of], 1, idx.clamp(max=149))
+    got = ix.sa_interval(pats, lens)
+    assert torch.equal(got[:, 0], lo[sel]) and torch.equal(got[:, 1], hi[sel])

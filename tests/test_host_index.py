@@ -1,0 +1,221 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports every
+declared symbol, and the native index builder (suffix array, K-mer table, prefix directory,
+image) agrees with the reference's outputs held in tests/golden/.  No compute kernels run here.
+"""
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import genie_smem_amd as g
+    g._native.build()
+    g._native.lib()
+    return g
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "genie_smem.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(genie_[a-z_0-9]+)\s*\(", hdr)))
+    assert sorted(pkg._native.SYMBOLS) == declared
+    lib = pkg._native.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.genie_abi_version() == 1
+    assert lib.genie_strerror(-7) == b"no RMI model installed"
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    monkeypatch.setattr(pkg._native, "_lib", None)
+    monkeypatch.setattr(pkg._native, "LIB_PATH", "/nonexistent/libgenie_smem.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg._native.lib()
+
+
+def test_compute_without_gpu_fails_loudly(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ix = pkg.GenieIndex.build(np.asarray([0, 1, 2, 3, 0, 1], np.uint8), 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ix.sa_interval(np.zeros((1, 2), np.uint8))
+    with pytest.raises(RuntimeError):
+        ix.to("cpu")
+
+
+# ------------------------------------------------------------------ SA + K-mer table vs reference
+def test_known_suffix_arrays(pkg):
+    k = G.known()
+    for name, alpha in (("mississippi", "imps"), ("paperex", "ACGT"), ("small_data", "ACGT")):
+        ix = pkg.GenieIndex.build(G.str_to_codes(k[name]["ref"], alpha), 0)
+        assert G.sa_sha256(ix.suffix_array()) == k[name]["fm"]["sa_sha256"], name
+    ix = pkg.GenieIndex.build(G.str_to_codes("CTCAATGC"), 2)
+    assert ix.suffix_array().tolist() == [9, 4, 5, 8, 3, 1, 7, 2, 6]
+    codes, lo, hi = ix.lut_arrays()
+    sa = ix.suffix_array()
+    got = {str(int(c)): [[int(a), int(b)], sa[a:b + 1].tolist()] for c, a, b in zip(codes, lo, hi)}
+    assert got == k["paperex"]["lut"]
+
+
+@pytest.mark.parametrize("ds", [d for d in G.DATASETS if G.have(d)])
+def test_index_matches_reference_digests(pkg, ds):
+    d, meta = G.load(ds)
+    ix = pkg.GenieIndex.build(d["ref_codes"], int(d["K"]))
+    sa = ix.suffix_array()
+    assert G.sa_sha256(sa) == meta["fm"]["sa_sha256"]
+    codes, lo, hi = ix.lut_arrays()
+    sha, npos, maxocc = G.lut_sha256(codes, lo, hi, sa)
+    assert (len(codes), sha, npos, maxocc) == (meta["lut"]["n_keys"], meta["lut"]["sha256"], meta["lut"]["n_pos"],
+                                               meta["lut"]["max_occ"])
+    # adopting the reference's own suffix array gives the same index image
+    ix2 = pkg.GenieIndex.build(d["ref_codes"], int(d["K"]), sa_one_based=sa.copy())
+    assert bytes(ix2.serialize().numpy()) == bytes(ix.serialize().numpy())
+
+
+def test_create_from_sa_rejects_garbage(pkg):
+    codes = np.asarray([0, 1, 2, 3, 0, 1, 2], np.uint8)
+    good = pkg.GenieIndex.build(codes, 0).suffix_array().copy()
+    bad = good.copy()
+    bad[1], bad[2] = bad[2], bad[1]
+    with pytest.raises(pkg._native.GenieError):
+        pkg.GenieIndex.build(codes, 0, sa_one_based=bad)
+    bad = good.copy()
+    bad[3] = bad[4]
+    with pytest.raises(pkg._native.GenieError):
+        pkg.GenieIndex.build(codes, 0, sa_one_based=bad)
+    with pytest.raises(pkg._native.GenieError):
+        pkg.GenieIndex.build(np.asarray([0, 4], np.uint8), 0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/SMEM/data"), reason="reference data files not present")
+def test_reference_checked_in_fixtures(pkg):
+    """The reference's own FM / LUT json fixtures (read as data, only where the reference exists)."""
+    import json
+    data = "/root/reference/SMEM/data"
+    for stem in ("small_data", "medium_data"):
+        with open(os.path.join(data, stem + ".fa")) as fh:
+            fh.readline()
+            seq = "".join(line.strip() for line in fh)
+        fm = json.load(open(os.path.join(data, stem + "-FM.json")))
+        ix = pkg.GenieIndex.build(G.str_to_codes(seq), 6)
+        assert ix.suffix_array().tolist() == fm["suffix_array"]
+    lut = json.load(open(os.path.join(data, "medium_data-LUT.json")))
+    assert lut["lut_size"] == 6
+    codes, lo, hi = ix.lut_arrays()
+    sa = ix.suffix_array()
+    got = {str(int(c)): [[int(a), int(b)], sa[a:b + 1].tolist()] for c, a, b in zip(codes, lo, hi)}
+    assert got == lut["lut"]
+
+
+# ------------------------------------------------------------------ image + prefix directory
+HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8I")
+
+
+def _parse(img):
+    f = HDR.unpack(bytes(img[:HDR.size]))
+    keys = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
+            "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
+    h = dict(zip(keys, f[:18]))
+    h["padtail"] = list(f[-8:])
+    return h
+
+
+def _dir_interval(h, dirv, code, m):
+    """Python mirror of dir_lb / dir_ub in kernels.hip."""
+    P = h["P"]
+    x = code << (2 * (P - m))
+    lb = int(dirv[x]) - sum(1 for l in range(m, P) if h["padtail"][l] == x)
+    y = (code + 1) << (2 * (P - m))
+    ub = int(dirv[y]) - sum(1 for l in range(1, P) if h["padtail"][l] == y)
+    return lb, ub
+
+
+@pytest.mark.parametrize("tail", ["", "A", "AAAAAAAA", "TTTTTTTT", "CAAAAAA", "GTTTTTT", "ACGTTTA", "TTTTTTA", "C"])
+@pytest.mark.parametrize("P", [3, 7])
+def test_prefix_directory_brute_force(pkg, tail, P):
+    rng = np.random.default_rng(len(tail) * 31 + P)
+    body = "".join("ACGT"[c] for c in rng.integers(0, 4, 300))
+    ref = body + tail
+    ix = pkg.GenieIndex.build(G.str_to_codes(ref), 4, dir_bits=P)
+    img = ix.serialize().numpy()
+    h = _parse(img)
+    assert h["magic"] == 0x58444947454E4547 and h["n"] == len(ref) and h["P"] == P and h["total_bytes"] == len(img)
+    dirv = np.frombuffer(bytes(img[h["off_dir"]:h["off_dir"] + 4 * h["dir_entries"]]), np.uint32)
+    sa0 = np.frombuffer(bytes(img[h["off_sa"]:h["off_sa"] + 4 * (len(ref) + 1)]), np.int32)
+    assert (sa0 + 1).tolist() == ix.suffix_array().tolist()
+    suffixes = [ref[s:] + "$" for s in sa0]
+    assert suffixes == sorted(suffixes)
+    assert dirv[-1] == len(ref) + 1
+    for m in range(1, P + 1):
+        for code in range(4 ** m):
+            pat = "".join("ACGT"[(code >> (2 * (m - 1 - j))) & 3] for j in range(m))
+            rows = [r for r, s in enumerate(suffixes) if s.startswith(pat)]
+            lb, ub = _dir_interval(h, dirv, code, m)
+            if rows:
+                assert (lb, ub) == (rows[0], rows[-1] + 1), (pat, tail)
+            else:
+                assert lb >= ub, (pat, tail)
+
+
+def test_packed_reference_and_lut_slots(pkg):
+    d, meta = G.load("medium_K6")
+    ix = pkg.GenieIndex.build(d["ref_codes"], 6)
+    img = ix.serialize().numpy()
+    h = _parse(img)
+    n = h["n"]
+    recs = np.frombuffer(bytes(img[h["off_ref"]:h["off_ref"] + 16 * h["ref_recs"]]), np.uint64).reshape(-1, 2)
+    assert (recs[:-1, 1] == recs[1:, 0]).all()
+    words = recs[:, 0]
+    bases = np.zeros(len(words) * 32, np.uint8)
+    for j in range(32):
+        bases[j::32] = (words >> np.uint64(62 - 2 * j)) & np.uint64(3)
+    assert (bases[:n] == d["ref_codes"]).all() and not bases[n:].any()
+    slots = np.frombuffer(bytes(img[h["off_lut"]:h["off_lut"] + 16 * h["lut_slots"]]), np.int32).reshape(-1, 4)
+    used = slots[slots[:, 1] >= 0]
+    codes, lo, hi = ix.lut_arrays()
+    assert len(used) == len(codes) == h["lut_keys"]
+    order = np.argsort(used[:, 0].astype(np.uint32))
+    assert (used[order, 0].astype(np.uint32) == codes).all() and (used[order, 1] == lo).all() and (used[order, 2] == hi).all()
+
+
+# ------------------------------------------------------------------ RMI host side
+@pytest.mark.parametrize("ds", [d for d in ("syn100k_K15",) if G.have(d)])
+def test_rmi_predict_bit_exact_with_reference_coefficients(pkg, ds):
+    d, _ = G.load(ds)
+    K = int(d["K"])
+    for tag in sorted({k.split(".")[0] for k in d if k.startswith("g4_")}):
+        ex = [int(x) for x in d[f"{tag}.experts"]]
+        rmi = pkg.RMI.from_coefficients(ex, [d[f"{tag}.coef{l}"] for l in range(len(ex) + 1)],
+                                        [d[f"{tag}.icpt{l}"] for l in range(len(ex) + 1)])
+        w = 4 ** np.arange(K - 1, -1, -1, dtype=np.int64)
+        codes = (d[f"{tag}.kmers"].astype(np.int64) * w).sum(1)
+        assert (rmi.predict(codes.reshape(-1, 1)) == d[f"{tag}.pred"]).all()
+
+
+def test_rmi_fit_is_a_usable_model(pkg):
+    d, _ = G.load("syn10k_K8")
+    m = pkg.ExactMatch("syn10k.fa")
+    m.set_reference(G.codes_to_str(d["ref_codes"]))
+    r = pkg.RMI_LUT([10, 100], 8, "syn10k.fa", matcher=m)
+    r.train_RMI()
+    assert [len(l) for l in r.rmi.models] == [1, 10, 100]
+    sa = np.asarray(m.host_index(8).suffix_array(), np.int64)
+    rows = np.nonzero(sa - 1 + 8 <= len(d["ref_codes"]))[0]
+    codes = d["ref_codes"].astype(np.int64)
+    key = np.zeros(len(rows), np.int64)
+    for j in range(8):
+        key = (key << 2) | codes[sa[rows] - 1 + j]
+    err = np.abs(r.rmi.predict(key.reshape(-1, 1)) - rows)
+    assert err.mean() < 30 and err.max() < 400
+    # scalar API shape: array of one float64, like the reference's rmi_predict
+    q = G.codes_to_str(d["ref_codes"][100:108])
+    assert r.rmi_predict(q).shape == (1,)
