@@ -124,6 +124,8 @@ def main():
     offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=device)
     out = torch.empty((n_reads * 40, 4), dtype=torch.int32, device=device)      # CSR rows (>= 3x the mean count)
     tmp = torch.empty(max(int(g._native.lib().genie_compact_tmp_bytes(n_reads)), 16), dtype=torch.uint8, device=device)
+    ws_bytes = int(g._native.lib().genie_find_smems_workspace_bytes(n_reads, L))
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device)
 
     import ctypes as C
     lib = g._native.lib()
@@ -138,7 +140,7 @@ def main():
         if i is not None:
             ev[i][0].record(stream)
         g._native.check(lib.genie_find_smems(ix._h, mode_id, P(reads), None, n_reads, L, L, 1, P(counts), P(slots), cap,
-                                             P(status), sp), "genie_find_smems")
+                                             P(status), P(ws), ws_bytes, sp), "genie_find_smems")
         if i is not None:
             ev[i][1].record(stream)
         g._native.check(lib.genie_compact_smems(P(counts), P(slots), n_reads, cap, P(offsets), P(out), out.shape[0],

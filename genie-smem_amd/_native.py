@@ -27,7 +27,8 @@ SYMBOLS = [
     "genie_abi_version", "genie_index_create", "genie_index_create_from_sa", "genie_index_set_rmi",
     "genie_index_info", "genie_index_suffix_array", "genie_index_lut_arrays", "genie_index_blob_bytes",
     "genie_index_serialize", "genie_index_open", "genie_index_to_device", "genie_index_destroy",
-    "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_compact_tmp_bytes",
+    "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_workspace_bytes",
+    "genie_compact_tmp_bytes",
     "genie_compact_smems", "genie_launch_info", "genie_strerror", "genie_last_hip_error",
 ]
 
@@ -49,7 +50,7 @@ class GenieError(RuntimeError):
 
 def build(force=False):
     """Compile libgenie_smem.so for gfx950 with hipcc (csrc/Makefile), in-tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "capi.cpp", "index_host.cpp", "genie_internal.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "short_read_kernel.inc", "capi.cpp", "index_host.cpp", "genie_internal.h", "Makefile")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "genie_smem.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
@@ -88,7 +89,8 @@ def lib():
         "genie_index_destroy": (None, [vp]),
         "genie_sa_interval": (C.c_int, [vp, vp, vp, i64, i32, i32, vp, vp]),
         "genie_seed_lookup": (C.c_int, [vp, i32, vp, i64, vp, vp, vp]),
-        "genie_find_smems": (C.c_int, [vp, i32, vp, vp, i64, i32, i32, i32, vp, vp, i32, vp, vp]),
+        "genie_find_smems": (C.c_int, [vp, i32, vp, vp, i64, i32, i32, i32, vp, vp, i32, vp, vp, i64, vp]),
+        "genie_find_smems_workspace_bytes": (i64, [i64, i32]),
         "genie_compact_tmp_bytes": (i64, [i64]),
         "genie_compact_smems": (C.c_int, [vp, vp, i64, i32, vp, vp, i64, vp, vp]),
         "genie_launch_info": (C.c_int, [vp, i32, i32, i32p, i32p, i32p]),

@@ -213,7 +213,8 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
 
 int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
                      int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
-                     int32_t *d_slots, int32_t cap, int32_t *d_status, void *stream)
+                     int32_t *d_slots, int32_t cap, int32_t *d_status, void *d_workspace, int64_t workspace_bytes,
+                     void *stream)
 {
     int rc = ready(ix);
     if (rc) return rc;
@@ -225,7 +226,13 @@ int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads
     if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
     if ((reinterpret_cast<uintptr_t>(d_slots) & 15) != 0) return GENIE_E_INVALID;
     return launch_find_smems(ix, mode, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, cap,
-                             d_status, stream);
+                             d_status, d_workspace, workspace_bytes, stream);
+}
+
+int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len)
+{
+    if (N < 0 || max_len < 0) return (int64_t)GENIE_E_INVALID;
+    return find_smems_workspace_bytes(N, max_len);
 }
 
 int64_t genie_compact_tmp_bytes(int64_t N) { return N < 0 ? (int64_t)GENIE_E_INVALID : compact_tmp_bytes(N); }

@@ -73,6 +73,21 @@ __device__ __forceinline__ uint64_t rwin(const RefRec *ref, int pos)
     return funnel(v.x, v.y, (pos & 31) * 2);
 }
 
+// Where a packed query lives.  QWords: 8-byte words (LDS scratch of the wave that packed it).
+// QRecs: the 16-byte overlapping records {w[i], w[i+1]} that K_A writes to global memory for
+// K_B -- every 32-base window is ONE 16-byte ALIGNED load.  (Two adjacent 8-byte global loads
+// get merged by the compiler into a dwordx4 at an 8-byte-aligned address; on MI355X that form
+// returned wrong window words under load in the lane-per-read kernel -- found by the 1M-read
+// parity test -- so global windows are always fetched as aligned records.)
+struct QWords {
+    const uint64_t *p;
+    __device__ __forceinline__ uint64_t win(int pos) const { return qwin(p, pos); }
+};
+struct QRecs {
+    const RefRec *p;
+    __device__ __forceinline__ uint64_t win(int pos) const { return rwin(p, pos); }
+};
+
 // ------------------------------------------------------------------ prefix directory (LDS)
 // dir[x] = number of SA rows whose suffix is smaller than the P-mer string x.  Rows whose
 // suffix has fewer than P bases ("tails", P-1 of them plus the '$' row) need the two
@@ -109,7 +124,8 @@ struct Cmp {
 
 // Compare q[a : a+m) with the reference suffix starting at 0-based s, the first `skip` bases
 // being known equal (skip <= min(m, n - s)).
-__device__ __forceinline__ Cmp cmp_suffix(const DevIndex &ix, const uint64_t *qp, int a, int m, int s, int skip)
+template <class Q>
+__device__ __forceinline__ Cmp cmp_suffix(const DevIndex &ix, const Q qp, int a, int m, int s, int skip)
 {
     const int avail = ix.n - s;
     const int lim = m < avail ? m : avail;
@@ -117,7 +133,7 @@ __device__ __forceinline__ Cmp cmp_suffix(const DevIndex &ix, const uint64_t *qp
     bool less = false;
     bool diff = false;
     while (l < lim) {
-        const uint64_t xq = qwin(qp, a + l), xr = rwin(ix.ref, s + l);
+        const uint64_t xq = qp.win(a + l), xr = rwin(ix.ref, s + l);
         const uint64_t x = xq ^ xr;
         if (x) {
             l += __clzll((long long)x) >> 1;
@@ -241,7 +257,8 @@ __device__ __forceinline__ bool rmi_lookup(const DevIndex &ix, const RmiModel *l
 // ------------------------------------------------------------------ matching statistics
 // Longest prefix of q[a:L) that occurs in the reference (its length), by bounded binary search
 // over the SA rows [lo, hi) that all share the first `skip` bases with the pattern.
-__device__ __forceinline__ int ms_search(const DevIndex &ix, const uint64_t *qp, int a, int m, int lo, int hi, int skip)
+template <class Q>
+__device__ __forceinline__ int ms_search(const DevIndex &ix, const Q qp, int a, int m, int lo, int hi, int skip)
 {
     int best = skip;
     while (lo < hi) {
@@ -254,11 +271,12 @@ __device__ __forceinline__ int ms_search(const DevIndex &ix, const uint64_t *qp,
 }
 
 // Generic path: P-mer directory bucket, then ms_search; shorter than P bases => directory only.
-__device__ __forceinline__ int ms_generic(const DevIndex &ix, const uint32_t *dir, const uint64_t *qp, int a, int L)
+template <class Q>
+__device__ __forceinline__ int ms_generic(const DevIndex &ix, const uint32_t *dir, const Q qp, int a, int L)
 {
     const int m = L - a;
     const int P = ix.P;
-    const uint64_t w = qwin(qp, a);
+    const uint64_t w = qp.win(a);
     int t = m;
     if (m >= P) {
         const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
@@ -276,11 +294,12 @@ __device__ __forceinline__ int ms_generic(const DevIndex &ix, const uint32_t *di
 
 // Inclusive SA interval of q[a : a+m) (== ExactMatch.exact_match_back_prop of that substring);
 // (-1,-1) if absent, (0,n) for the empty pattern.
-__device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *dir, const uint64_t *qp, int a, int m)
+template <class Q>
+__device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *dir, const Q qp, int a, int m)
 {
     if (m == 0) return make_int2(0, ix.n);
     const int P = ix.P;
-    const uint64_t w = qwin(qp, a);
+    const uint64_t w = qp.win(a);
     if (m <= P) {
         const uint32_t code = (uint32_t)(w >> (64 - 2 * m));
         const int lb = (int)dir_lb(ix, dir, code, m), ub = (int)dir_ub(ix, dir, code, m);
@@ -398,7 +417,7 @@ __device__ __forceinline__ bool seq_check(const DevIndex &ix, const uint32_t *di
 {
     const int K = ix.K;
     if (pc == c + 1) return rfl((int)ws.fwd[c]) >= c + K + 1;
-    const int2 iv = sa_interval(ix, dir, ws.qp, c, K);             // wave-uniform inputs
+    const int2 iv = sa_interval(ix, dir, QWords{ws.qp}, c, K);     // wave-uniform inputs
     if (iv.x < 0) return false;
     const uint32_t want = (uint32_t)(qwin(ws.qp, pc) >> (64 - 2 * K));
     bool found = false;
@@ -423,7 +442,7 @@ __global__ void __launch_bounds__(1024) find_smems_kernel(DevIndex ix, const uin
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = rfl((int)(threadIdx.x >> 6));       // wave-uniform by construction
     const int waves_per_block = blockDim.x >> 6;
 
     // ---- stage the read-only seed tables in LDS (once per persistent block)
@@ -470,11 +489,11 @@ __global__ void __launch_bounds__(1024) find_smems_kernel(DevIndex ix, const uin
                     const bool hit = MODE == GENIE_MODE_LUT ? lut_probe(ix, code, lo, hi)
                                                             : rmi_lookup(ix, leaf, code, lo, hi, nullptr);
                     if (hit) {                         // forward extension from the seed interval
-                        len = ms_search(ix, ws.qp, a, L - a, lo, hi + 1, K);
+                        len = ms_search(ix, QWords{ws.qp}, a, L - a, lo, hi + 1, K);
                         seeded = true;
                     }
                 }
-                if (!seeded) len = ms_generic(ix, dir, ws.qp, a, L);
+                if (!seeded) len = ms_generic(ix, dir, QWords{ws.qp}, a, L);
                 ws.fwd[a] = (uint16_t)(a + len);
                 mymax = len > mymax ? len : mymax;
             }
@@ -580,7 +599,7 @@ __global__ void __launch_bounds__(1024) find_smems_kernel(DevIndex ix, const uin
             for (int t = lane; t < nout; t += kWave) {
                 const uint32_t e = ws.emit[t];
                 const int k = (int)(e & 0xFFFF), j = (int)(e >> 16);
-                const int2 iv = sa_interval(ix, dir, ws.qp, k, j - k);
+                const int2 iv = sa_interval(ix, dir, QWords{ws.qp}, k, j - k);
                 slots[r * (long long)cap + t] = make_int4(k, j, iv.x, iv.y);
             }
             if (cnt > cap) st = GENIE_READ_OVERFLOW;
@@ -593,6 +612,8 @@ __global__ void __launch_bounds__(1024) find_smems_kernel(DevIndex ix, const uin
     }
 }
 
+#include "short_read_kernel.inc"
+
 // ------------------------------------------------------------------ K1: batched exact_match_back_prop
 __global__ void __launch_bounds__(256) sa_interval_kernel(DevIndex ix, const uint8_t *__restrict__ pats,
                                                           const int32_t *__restrict__ lens, long long N, int stride,
@@ -600,7 +621,7 @@ __global__ void __launch_bounds__(256) sa_interval_kernel(DevIndex ix, const uin
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = rfl((int)(threadIdx.x >> 6));       // wave-uniform by construction
     const int waves_per_block = blockDim.x >> 6;
     uint32_t *dir = reinterpret_cast<uint32_t *>(smem);
     const int dir_bytes = (ix.dir_entries * 4 + 15) & ~15;
@@ -612,7 +633,7 @@ __global__ void __launch_bounds__(256) sa_interval_kernel(DevIndex ix, const uin
         const int L = lens ? lens[r] : fixed_len;
         int2 iv = make_int2(-2, -2);
         if (L >= 0 && L <= Lmax && load_and_pack(pats + r * (long long)stride, L, Lmax, ws, lane))
-            iv = sa_interval(ix, dir, ws.qp, 0, L);          // every lane computes the same interval
+            iv = sa_interval(ix, dir, QWords{ws.qp}, 0, L);  // every lane computes the same interval
         if (lane == 0) out[r] = iv;
         wave_lds_fence();
     }
@@ -737,7 +758,17 @@ std::string g_err;
 
 struct Geometry {
     int grid, block, lds, leaf_in_lds, Lmax;
+    int ns;          // > 0: short-read pipeline (K_A + K_B) for reads of at most 255 bases
+    int fwd_stride;  // bytes per fwd[] row in the workspace (multiple of 4, odd number of dwords)
 };
+
+inline int fwd_row_bytes(int max_len)
+{
+    int dw = (max_len + 3) / 4;
+    if (dw < 1) dw = 1;
+    if ((dw & 1) == 0) dw++;
+    return dw * 4;
+}
 
 int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
 {
@@ -750,7 +781,8 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
         if (cnt * 16 <= 48 * 1024) leaf_bytes = cnt * 16;
     }
     const int Lmax = std::max(32, (max_len + 31) / 32 * 32);
-    const int per_wave = scratch_bytes(Lmax);
+    const int ns = max_len <= 255 ? std::max(1, (max_len + 63) / 64) : 0;
+    const int per_wave = ns ? (2 * ns + 2) * 8 : scratch_bytes(Lmax);
     int waves = (lds_cap - dir_bytes - leaf_bytes) / per_wave;
     if (waves < 1) return GENIE_E_TOO_LONG;
     if (waves > 16) waves = 16;
@@ -771,14 +803,89 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     g->lds = lds;
     g->leaf_in_lds = leaf_bytes > 0;
     g->Lmax = Lmax;
+    g->ns = ns;
+    g->fwd_stride = fwd_row_bytes(max_len);
+    return GENIE_OK;
+}
+
+struct Workspace {
+    uint8_t *fwd;
+    RefRec *qp;          // 2*ns records of 16 bytes per read
+    int32_t *status;
+};
+
+inline int64_t ws_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+inline int64_t workspace_bytes_for(int64_t N, int max_len)
+{
+    if (max_len > 255) return 0;
+    const int ns = std::max(1, (max_len + 63) / 64);
+    return ws_align(N * (int64_t)fwd_row_bytes(max_len)) + ws_align(N * (int64_t)(2 * ns) * 16) + ws_align(N * 4) + 256;
+}
+
+template <int MODE, int NS>
+int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                 int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots, int32_t cap,
+                 int32_t *d_status, const Workspace &ws, hipStream_t s)
+{
+    int32_t *st = d_status ? d_status : ws.status;
+    auto ka = match_stats_kernel<MODE, NS>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
+                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, st, g.leaf_in_lds);
+    HIP_TRY(hipGetLastError());
+    auto kb = traverse_kernel<MODE>;
+    const int tb = 256;
+    const int lds_b = tb * g.fwd_stride;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+    hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, 2 * NS, d_counts,
+                       reinterpret_cast<int4 *>(d_slots), cap, st);
+    HIP_TRY(hipGetLastError());
+    // K_C: intervals, 16 lanes per read, persistent blocks with the directory in LDS
+    const int lds_c = (ix->dev.dir_entries * 4 + 15) & ~15;
+    const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
+    int blocks_c = 160 * 1024 / lds_c;
+    blocks_c = blocks_c > 2 ? 2 : (blocks_c < 1 ? 1 : blocks_c);
+    long long grid_c = (long long)cus * blocks_c;
+    const long long need_c = (N + 63) / 64;
+    if (grid_c > need_c) grid_c = need_c;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(interval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
+    hipLaunchKernelGGL(interval_kernel, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, d_counts,
+                       reinterpret_cast<int4 *>(d_slots), cap, ws.qp, 2 * NS);
+    HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
 
 template <int MODE>
 int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
                      int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
-                     int32_t cap, int32_t *d_status, hipStream_t s)
+                     int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, hipStream_t s)
 {
+    if (g.ns > 0) {
+        if (!d_ws || ws_bytes < workspace_bytes_for(N, fixed_len) || (reinterpret_cast<uintptr_t>(d_ws) & 255) != 0)
+            return GENIE_E_CAPACITY;
+        Workspace ws;
+        uint8_t *p = reinterpret_cast<uint8_t *>(d_ws);
+        ws.fwd = p;
+        p += ws_align(N * (int64_t)g.fwd_stride);
+        ws.qp = reinterpret_cast<RefRec *>(p);
+        p += ws_align(N * (int64_t)(2 * g.ns) * 16);
+        ws.status = reinterpret_cast<int32_t *>(p);
+#define GENIE_SHORT(NS_)                                                                                        \
+    case NS_:                                                                                                   \
+        return launch_short<MODE, NS_>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, \
+                                       cap, d_status, ws, s)
+        switch (g.ns) {
+            GENIE_SHORT(1);
+            GENIE_SHORT(2);
+            GENIE_SHORT(3);
+            GENIE_SHORT(4);
+        default:
+            return GENIE_E_INVALID;
+        }
+#undef GENIE_SHORT
+    }
     auto kern = find_smems_kernel<MODE>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
@@ -814,9 +921,11 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
     return GENIE_OK;
 }
 
+int64_t find_smems_workspace_bytes(int64_t N, int32_t max_len) { return workspace_bytes_for(N, max_len); }
+
 int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
                       int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
-                      int32_t cap, int32_t *d_status, void *stream)
+                      int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, void *stream)
 {
     if (N == 0) return GENIE_OK;
     Geometry g;
@@ -827,13 +936,13 @@ int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_read
     switch (mode) {
     case GENIE_MODE_BWA:
         return launch_find_mode<GENIE_MODE_BWA>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
-                                                cap, d_status, s);
+                                                cap, d_status, d_ws, ws_bytes, s);
     case GENIE_MODE_LUT:
         return launch_find_mode<GENIE_MODE_LUT>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
-                                                cap, d_status, s);
+                                                cap, d_status, d_ws, ws_bytes, s);
     case GENIE_MODE_RMI:
         return launch_find_mode<GENIE_MODE_RMI>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
-                                                cap, d_status, s);
+                                                cap, d_status, d_ws, ws_bytes, s);
     }
     return GENIE_E_INVALID;
 }

@@ -209,10 +209,12 @@ class GenieIndex:
             counts.zero_()
             status.zero_()
             return counts, slots, status
+        ws_bytes = int(N.lib().genie_find_smems_workspace_bytes(n_reads, fixed))
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             N.check(N.lib().genie_find_smems(self._h, N.MODES[mode], _ptr(reads), _ptr(lens), n_reads, stride, fixed,
-                                             int(min_len), _ptr(counts), _ptr(slots), cap, _ptr(status),
-                                             _stream(self.device)), "genie_find_smems")
+                                             int(min_len), _ptr(counts), _ptr(slots), cap, _ptr(status), _ptr(ws),
+                                             ws_bytes, _stream(self.device)), "genie_find_smems")
         return counts, slots, status
 
     def compact(self, counts, slots, out=None):

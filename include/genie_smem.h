@@ -159,10 +159,15 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
  * d_slots[(r*cap + t)*4 + {0,1,2,3}] = (start, end, lo, hi) of its t-th SMEM in the
  * reference's emission order: the substring read[start:end) and its SA interval [lo, hi].
  * d_status[r] (may be NULL) = GENIE_READ_* code.  `cap` slots per read (cap >= max read
- * length never overflows). */
+ * length never overflows).
+ * d_workspace: 256-byte aligned device scratch of genie_find_smems_workspace_bytes(N, max_len)
+ * bytes (matching statistics handed from the search kernel to the traversal kernel; 0 bytes --
+ * pointer may be NULL -- for reads longer than 255 bases, which take the single-kernel path). */
+int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len);
 int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
                      int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
-                     int32_t *d_slots, int32_t cap, int32_t *d_status, void *stream);
+                     int32_t *d_slots, int32_t cap, int32_t *d_status, void *d_workspace, int64_t workspace_bytes,
+                     void *stream);
 
 /* Compact the slotted output to CSR: d_offsets[N+1] (exclusive prefix sum of min(count,cap))
  * and d_out[total*4].  d_tmp: scratch of genie_compact_tmp_bytes(N) bytes. */

@@ -286,22 +286,31 @@ def test_absent_base_is_flagged(pkg):
 
 
 # ------------------------------------------------------------------ full-size properties (config 2/3 shape)
-def test_full_size_properties(pkg):
-    """1M x 150 bp reads on the 100 kb reference: size-independent properties -- the three
-    traversals agree, every SMEM re-searches to its own interval, covers are monotone."""
+def test_full_size_properties(pkg, oracle_mod):
+    """1M x 150 bp reads on the 100 kb reference (BASELINE config 1/2 shape).  Size-independent
+    properties: the three traversals agree bit for bit, repeated runs are identical, covers are
+    monotone, every emitted substring re-searches to its own interval with the batched exact-match
+    kernel -- plus a 60 000-read slice compared row by row with the CPU oracle.
+    (This test is the guard that caught wrong intervals from an earlier kernel structure that
+    only misbehaved at full occupancy; keep it at full size.)"""
     import torch
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
     ix = _index_for(pkg, "syn100k_K15", "rmi")
     n_reads = 1_000_000
-    rd = torch.as_tensor(B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, 1002)).cuda()
+    rd_np = B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, 1002)
+    rd = torch.as_tensor(rd_np).cuda()
     res = {}
-    for algo in ("bwa", "lut", "rmi"):
-        offsets, smems, st = ix.find_smems(algo, rd)
-        assert int(st.abs().sum().item()) == 0
-        res[algo] = (offsets, smems)
-    assert torch.equal(res["bwa"][0], res["lut"][0]) and torch.equal(res["bwa"][1], res["lut"][1])
-    assert torch.equal(res["rmi"][0], res["lut"][0]) and torch.equal(res["rmi"][1], res["lut"][1])
+    for rep in range(2):
+        for algo in ("bwa", "lut", "rmi"):
+            offsets, smems, st = ix.find_smems(algo, rd)
+            assert int(st.abs().sum().item()) == 0
+            if rep == 0:
+                res[algo] = (offsets, smems)
+            else:
+                assert torch.equal(res[algo][0], offsets) and torch.equal(res[algo][1], smems), algo   # deterministic
+    for algo in ("bwa", "rmi"):
+        assert torch.equal(res[algo][0], res["lut"][0]) and torch.equal(res[algo][1], res["lut"][1]), algo
     offsets, smems = res["lut"]
     start, end, lo, hi = smems[:, 0], smems[:, 1], smems[:, 2], smems[:, 3]
     assert bool(((start >= 0) & (start < end) & (end <= 150) & (lo >= 0) & (lo <= hi) & (hi <= ix.n)).all())
@@ -311,11 +320,22 @@ def test_full_size_properties(pkg):
     same_read = torch.ones(len(end) - 1, dtype=torch.bool, device=end.device)
     same_read[(offsets[1:-1] - 1)] = False
     assert bool((end[1:][same_read] > end[:-1][same_read]).all())
-    # re-search a sample of emitted substrings with the batched exact-match kernel
-    sel = torch.randperm(len(start), device=start.device)[:200000]
+    # re-search emitted substrings with the batched exact-match kernel (a different kernel)
+    sel = torch.randperm(len(start), device=start.device)[:400000]
     read_of = torch.searchsorted(offsets, sel, right=True) - 1
     lens = (end[sel] - start[sel]).to(torch.int32)
     idx = start[sel].long()[:, None] + torch.arange(150, device=rd.device)[None, :]
     pats = torch.gather(rd[read_of], 1, idx.clamp(max=149))
     got = ix.sa_interval(pats, lens)
     assert torch.equal(got[:, 0], lo[sel]) and torch.equal(got[:, 1], hi[sel])
+    # oracle, row by row, on slices taken from the start, the middle and the end of the batch
+    o = oracle_mod.Oracle(d["ref_codes"], int(d["K"]))
+    off = offsets.cpu().numpy()
+    sm = smems.cpu().numpy()
+    for a in (0, 480_000, 980_000):
+        b = a + 20_000
+        counts, want = o.find_smems_batch("lut", rd_np[a:b], nthreads=16)
+        assert (np.diff(off[a:b + 1]) == counts).all()
+        rows = np.repeat(np.arange(b - a), counts)
+        tpos = np.arange(len(rows)) - np.repeat(off[a:b] - off[a], counts)
+        assert (want[rows, tpos] == sm[off[a]:off[b]]).all()
