@@ -10,7 +10,7 @@
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -30,6 +30,18 @@ struct RmiModel {
     double icpt;
 };
 
+// One suffix-array row: the 0-based suffix start and, inline, the 32 bases that FOLLOW the first P
+// bases of that suffix (packed like the reference, zero padded past the end).  A binary-search
+// probe is ONE aligned 16-byte load: the P-mer directory has already fixed the first P bases, the
+// inline key decides the next 32 -- the packed reference is only touched when more than P+32
+// bases are equal (repeats).
+struct SaRec {
+    int32_t s;
+    int32_t pad;
+    uint64_t key;
+};
+static_assert(sizeof(SaRec) == 16, "SaRec must be one 16-byte load");
+
 // Two consecutive 32-base words of the packed reference, so that any 32-base window is ONE
 // aligned 16-byte load: rec[i] = { W[i], W[i+1] }.
 struct RefRec {
@@ -46,7 +58,7 @@ struct BlobHeader {
     int64_t n;
     int32_t K;
     int32_t P;
-    int64_t off_sa;       // int32  [n+1]        0-based suffix starts, row 0 = n ('$')
+    int64_t off_sa;       // SaRec  [n+1]        suffix start + inline 32-base key; row 0 = the '$' suffix
     int64_t off_ref;      // RefRec [ref_recs]   big-endian-in-word 2-bit bases, zero padded
     int64_t off_dir;      // uint32 [4^P + 1]    prefix directory (rows < P-mer string)
     int64_t off_lut;      // LutSlot[lut_slots]
@@ -67,7 +79,7 @@ static_assert(sizeof(BlobHeader) <= GENIE_HEADER_BYTES, "header size");
 
 // What the kernels receive by value (kernarg): raw device pointers + scalars.
 struct DevIndex {
-    const int32_t *sa;
+    const SaRec *sa;
     const RefRec *ref;
     const uint32_t *dir;
     const LutSlot *lut;
@@ -93,6 +105,7 @@ struct HostIndex {
     int32_t K = 0, P = 0;
     std::vector<uint8_t> codes;
     std::vector<int32_t> sa0;            // 0-based starts, row 0 = n
+    std::vector<SaRec> sarec;            // device layout of the suffix array
     std::vector<int32_t> sa1;            // reference convention (1-based), for the host API
     std::vector<RefRec> ref;
     std::vector<uint32_t> dir;

@@ -125,6 +125,18 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
         h->sa1.resize((size_t)rows);
         for (int64_t r = 0; r < rows; r++) h->sa1[(size_t)r] = h->sa0[(size_t)r] + 1;
         pack_reference(codes, n, h->ref);
+        // device suffix-array records: start + the 32 bases after the P-base prefix
+        h->sarec.resize((size_t)rows);
+        for (int64_t r = 0; r < rows; r++) {
+            const int64_t s = h->sa0[(size_t)r], pos = s + P;
+            uint64_t key = 0;
+            if (pos < n) {
+                const RefRec &rr = h->ref[(size_t)(pos >> 5)];
+                const int sh = (int)(pos & 31) * 2;
+                key = sh ? (rr.w0 << sh) | (rr.w1 >> (64 - sh)) : rr.w0;
+            }
+            h->sarec[(size_t)r] = SaRec{(int32_t)s, 0, key};
+        }
 
         // Prefix directory: dir[x] = number of rows whose suffix is lexicographically smaller
         // than the P-mer string x (x = 4^P: all rows).  A row whose suffix holds >= P bases and
@@ -165,7 +177,7 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                 }
             }
             const uint64_t m = h->lut_code.size();
-            uint64_t slots = m + m / 2 + 8;                        // load factor <= 2/3
+            uint64_t slots = 2 * m + 8;                            // load factor <= 1/2
             h->lut_slots.assign((size_t)slots, LutSlot{0, -1, -1, 0});
             for (uint64_t i = 0; i < m; i++) {
                 uint32_t p = lut_hash(h->lut_code[(size_t)i], (uint32_t)slots);
@@ -208,7 +220,7 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     for (int l = 0; l < 8; l++) hdr->padtail[l] = h.padtail[l];
     int64_t off = GENIE_HEADER_BYTES;
     hdr->off_sa = off;
-    off = align_up(off + (int64_t)h.sa0.size() * 4);
+    off = align_up(off + (int64_t)h.sarec.size() * (int64_t)sizeof(SaRec));
     hdr->off_ref = off;
     off = align_up(off + (int64_t)h.ref.size() * (int64_t)sizeof(RefRec));
     hdr->off_dir = off;
@@ -228,7 +240,7 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     uint8_t *p = (uint8_t *)dst;
     memset(p, 0, (size_t)hdr.total_bytes);
     memcpy(p, &hdr, sizeof(hdr));
-    memcpy(p + hdr.off_sa, h.sa0.data(), h.sa0.size() * 4);
+    memcpy(p + hdr.off_sa, h.sarec.data(), h.sarec.size() * sizeof(SaRec));
     memcpy(p + hdr.off_ref, h.ref.data(), h.ref.size() * sizeof(RefRec));
     memcpy(p + hdr.off_dir, h.dir.data(), h.dir.size() * 4);
     memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
@@ -245,7 +257,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     if ((reinterpret_cast<uintptr_t>(d_blob) & 15) != 0) return GENIE_E_INVALID;
     const uint8_t *p = (const uint8_t *)d_blob;
     memset(out, 0, sizeof(*out));
-    out->sa = (const int32_t *)(p + hdr.off_sa);
+    out->sa = (const SaRec *)(p + hdr.off_sa);
     out->ref = (const RefRec *)(p + hdr.off_ref);
     out->dir = (const uint32_t *)(p + hdr.off_dir);
     out->lut = (const LutSlot *)(p + hdr.off_lut);

@@ -150,6 +150,40 @@ __device__ __forceinline__ Cmp cmp_suffix(const DevIndex &ix, const Q qp, int a,
     return {l, less};
 }
 
+// The same comparison against a suffix-array record, the first P bases known equal (every row
+// of a directory bucket): the inline key decides the next 32 bases without touching the reference.
+// `xq` = qp.win(a + P), hoisted by the caller.
+template <class Q>
+__device__ __forceinline__ Cmp cmp_rec(const DevIndex &ix, const Q qp, int a, int m, const SaRec rec, uint64_t xq)
+{
+    const int avail = ix.n - rec.s;
+    const int lim = m < avail ? m : avail;
+    int l = ix.P;
+    bool less;
+    const uint64_t x = xq ^ rec.key;
+    if (x) {
+        l += __clzll((long long)x) >> 1;
+        less = rec.key < xq;
+        if (l >= lim) { l = lim; less = lim < m; }
+    } else if (l + 32 >= lim) {
+        l = lim;
+        less = lim < m;
+    } else {                                   // more than P + 32 equal bases: continue in the reference
+        return cmp_suffix(ix, qp, a, m, rec.s, l + 32);
+    }
+    return {l, less};
+}
+
+__device__ __forceinline__ SaRec load_rec(const SaRec *sa, int row)
+{
+    const int4 v = *reinterpret_cast<const int4 *>(sa + row);          // one 16-byte load
+    SaRec r;
+    r.s = v.x;
+    r.pad = 0;
+    r.key = ((uint64_t)(uint32_t)v.w << 32) | (uint32_t)v.z;
+    return r;
+}
+
 // ------------------------------------------------------------------ seeds
 // LUT mode: `encoded_sub in self.lut.lut` + `self.lut.lut[encoded_sub][0]` (SMEM.py:65-70) as an
 // open-addressing probe of the K-mer hash table (one 16-byte slot per probe).
@@ -187,7 +221,7 @@ __device__ __forceinline__ double rmi_predict(const DevIndex &ix, const RmiModel
 // -1 suffix < kmer, 0 kmer is a prefix of the suffix, +1 suffix > kmer.
 __device__ __forceinline__ int kmer_cmp_row(const DevIndex &ix, int r, uint32_t code)
 {
-    const int s = ix.sa[r];
+    const int s = ix.sa[r].s;
     const int avail = ix.n - s;
     if (avail == 0) return -1;
     const uint64_t w = rwin(ix.ref, s);
@@ -261,9 +295,12 @@ template <class Q>
 __device__ __forceinline__ int ms_search(const DevIndex &ix, const Q qp, int a, int m, int lo, int hi, int skip)
 {
     int best = skip;
+    const bool use_key = skip == ix.P;
+    const uint64_t xq = qp.win(a + ix.P);
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const Cmp c = cmp_suffix(ix, qp, a, m, ix.sa[mid], skip);
+        const SaRec rec = load_rec(ix.sa, mid);
+        const Cmp c = use_key ? cmp_rec(ix, qp, a, m, rec, xq) : cmp_suffix(ix, qp, a, m, rec.s, skip);
         best = c.l > best ? c.l : best;
         if (c.less) lo = mid + 1; else hi = mid;
     }
@@ -308,16 +345,17 @@ __device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *
     const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
     int lo = (int)dir[b];
     const int hi = (int)dir_ub(ix, dir, b, P);
+    const uint64_t xq = qp.win(a + P);
     int h = hi;
     while (lo < h) {                                    // first row whose suffix is not < pattern
         const int mid = (lo + h) >> 1;
-        if (cmp_suffix(ix, qp, a, m, ix.sa[mid], P).less) lo = mid + 1; else h = mid;
+        if (cmp_rec(ix, qp, a, m, load_rec(ix.sa, mid), xq).less) lo = mid + 1; else h = mid;
     }
     const int first = lo;
     h = hi;
     while (lo < h) {                                    // first row that no longer has it as prefix
         const int mid = (lo + h) >> 1;
-        if (cmp_suffix(ix, qp, a, m, ix.sa[mid], P).l >= m) lo = mid + 1; else h = mid;
+        if (cmp_rec(ix, qp, a, m, load_rec(ix.sa, mid), xq).l >= m) lo = mid + 1; else h = mid;
     }
     return first < lo ? make_int2(first, lo - 1) : make_int2(-1, -1);
 }
@@ -425,7 +463,7 @@ __device__ __forceinline__ bool seq_check(const DevIndex &ix, const uint32_t *di
         const int r = r0 + lane;
         bool ok = false;
         if (r <= iv.y) {
-            const int s1 = ix.sa[r] + 1;
+            const int s1 = ix.sa[r].s + 1;
             if (s1 + K <= ix.n) ok = (uint32_t)(rwin(ix.ref, s1) >> (64 - 2 * K)) == want;
         }
         found |= __any(ok) != 0;

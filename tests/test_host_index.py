@@ -150,7 +150,15 @@ def test_prefix_directory_brute_force(pkg, tail, P):
     h = _parse(img)
     assert h["magic"] == 0x58444947454E4547 and h["n"] == len(ref) and h["P"] == P and h["total_bytes"] == len(img)
     dirv = np.frombuffer(bytes(img[h["off_dir"]:h["off_dir"] + 4 * h["dir_entries"]]), np.uint32)
-    sa0 = np.frombuffer(bytes(img[h["off_sa"]:h["off_sa"] + 4 * (len(ref) + 1)]), np.int32)
+    recs = np.frombuffer(bytes(img[h["off_sa"]:h["off_sa"] + 16 * (len(ref) + 1)]), np.int32).reshape(-1, 4)
+    sa0 = recs[:, 0]
+    keys = np.frombuffer(bytes(img[h["off_sa"]:h["off_sa"] + 16 * (len(ref) + 1)]), np.uint64).reshape(-1, 2)[:, 1]
+    for r in (0, 1, len(ref) // 2, len(ref)):                     # inline key = 32 bases after the P-base prefix
+        want = 0
+        for j in range(32):
+            p_ = int(sa0[r]) + P + j
+            want |= ("ACGT".index(ref[p_]) if p_ < len(ref) else 0) << (62 - 2 * j)
+        assert int(keys[r]) == want
     assert (sa0 + 1).tolist() == ix.suffix_array().tolist()
     suffixes = [ref[s:] + "$" for s in sa0]
     assert suffixes == sorted(suffixes)
