@@ -20,6 +20,7 @@ MAX_K = 16
 MAX_READ_LEN = 8192
 MODE_BWA, MODE_LUT, MODE_RMI = 0, 1, 2
 MODES = {"bwa": MODE_BWA, "lut": MODE_LUT, "rmi": MODE_RMI}
+OPT_LUT_PROBE = 1
 READ_OK, READ_BAD_BASE, READ_TOO_SHORT, READ_ABSENT_BASE, READ_OVERFLOW = 0, 1, 2, 3, 4
 
 # every symbol include/genie_smem.h declares (tests check the library exports all of them)
@@ -29,7 +30,7 @@ SYMBOLS = [
     "genie_index_serialize", "genie_index_open", "genie_index_to_device", "genie_index_destroy",
     "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_workspace_bytes",
     "genie_compact_tmp_bytes",
-    "genie_compact_smems", "genie_launch_info", "genie_strerror", "genie_last_hip_error",
+    "genie_compact_smems", "genie_launch_info", "genie_index_set_option", "genie_strerror", "genie_last_hip_error",
 ]
 
 
@@ -94,6 +95,7 @@ def lib():
         "genie_compact_tmp_bytes": (i64, [i64]),
         "genie_compact_smems": (C.c_int, [vp, vp, i64, i32, vp, vp, i64, vp, vp]),
         "genie_launch_info": (C.c_int, [vp, i32, i32, i32p, i32p, i32p]),
+        "genie_index_set_option": (C.c_int, [vp, i32, i32]),
         "genie_strerror": (C.c_char_p, [C.c_int]),
         "genie_last_hip_error": (C.c_char_p, []),
     }

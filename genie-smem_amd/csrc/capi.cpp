@@ -252,6 +252,15 @@ int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int3
     return find_smems_geometry(ix, mode, max_len, grid, block, lds_bytes);
 }
 
+int genie_index_set_option(genie_index *ix, int32_t option, int32_t value)
+{
+    if (!ix) return GENIE_E_INVALID;
+    switch (option) {
+    case GENIE_OPT_LUT_PROBE: ix->opt_lut_probe = value != 0; return GENIE_OK;
+    default: return GENIE_E_INVALID;
+    }
+}
+
 const char *genie_strerror(int status)
 {
     switch (status) {

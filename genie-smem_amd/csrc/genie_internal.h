@@ -138,6 +138,7 @@ struct genie_index {
     void *owned_blob = nullptr;      // hipMalloc'ed by genie_index_to_device
     int64_t blob_bytes = 0;
     int32_t num_cus = 0;
+    int32_t opt_lut_probe = 0;       // GENIE_OPT_LUT_PROBE
 };
 
 // kernels.hip

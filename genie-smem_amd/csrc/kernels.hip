@@ -870,7 +870,7 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     auto ka = match_stats_kernel<MODE, NS>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
-                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, st, g.leaf_in_lds);
+                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, st, g.leaf_in_lds, ix->opt_lut_probe);
     HIP_TRY(hipGetLastError());
     auto kb = traverse_kernel<MODE>;
     const int tb = 256;

@@ -241,6 +241,9 @@ class GenieIndex:
         total = int(offsets[-1].item())
         return offsets, out[:total], status
 
+    def set_option(self, option, value):
+        N.check(N.lib().genie_index_set_option(self._h, int(option), int(value)), "genie_index_set_option")
+
     def launch_info(self, mode, max_len):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
         N.check(N.lib().genie_launch_info(self._h, N.MODES[mode], int(max_len), C.byref(g), C.byref(b), C.byref(l)),

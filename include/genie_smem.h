@@ -175,6 +175,14 @@ int64_t genie_compact_tmp_bytes(int64_t N);
 int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap,
                         int64_t *d_offsets, int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
 
+/* Launch-time options of an index handle.
+ * GENIE_OPT_LUT_PROBE (default 0): in LUT mode on the short-read path, also probe the K-mer hash
+ * table for every read position before the suffix-array search.  Results are identical either
+ * way; on MI355X the LDS-staged P-mer directory already narrows a position to a handful of rows,
+ * so the extra probe only costs time (measured: DESIGN.md) and is off by default. */
+enum { GENIE_OPT_LUT_PROBE = 1 };
+int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
+
 /* Launch geometry actually used by genie_find_smems for (mode, max read length): for reports. */
 int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
                       int32_t *lds_bytes);

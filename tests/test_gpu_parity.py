@@ -243,6 +243,21 @@ def test_vs_oracle_fresh_reads(pkg, oracle_mod, ds, L, kind, algo):
         assert rows[r].tolist() == out[r, :counts[r]].tolist(), r
 
 
+def test_lut_probe_option_changes_nothing(pkg):
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ix = _index(pkg, "syn100k_K15")
+    rd = B.reads_from_ref(d["ref_codes"], 3000, 150, 77)
+    a = ix.find_smems("lut", rd)
+    ix.set_option(pkg._native.OPT_LUT_PROBE, 1)
+    try:
+        b = ix.find_smems("lut", rd)
+    finally:
+        ix.set_option(pkg._native.OPT_LUT_PROBE, 0)
+    import torch
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_ragged_and_status(pkg, oracle_mod):
     d, _ = G.load("syn10k_K8")
     ix = _index(pkg, "syn10k_K8")
