@@ -30,7 +30,7 @@ SYMBOLS = [
     "genie_index_serialize", "genie_index_open", "genie_index_to_device", "genie_index_destroy",
     "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_workspace_bytes",
     "genie_compact_tmp_bytes",
-    "genie_compact_smems", "genie_launch_info", "genie_index_set_option", "genie_strerror", "genie_last_hip_error",
+    "genie_compact_smems", "genie_launch_info", "genie_index_set_option", "genie_index_set_stage_events", "genie_strerror", "genie_last_hip_error",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         "genie_compact_smems": (C.c_int, [vp, vp, i64, i32, vp, vp, i64, vp, vp]),
         "genie_launch_info": (C.c_int, [vp, i32, i32, i32p, i32p, i32p]),
         "genie_index_set_option": (C.c_int, [vp, i32, i32]),
+        "genie_index_set_stage_events": (C.c_int, [vp, vp, vp]),
         "genie_strerror": (C.c_char_p, [C.c_int]),
         "genie_last_hip_error": (C.c_char_p, []),
     }

@@ -261,6 +261,14 @@ int genie_index_set_option(genie_index *ix, int32_t option, int32_t value)
     }
 }
 
+int genie_index_set_stage_events(genie_index *ix, void *ev_search_begin, void *ev_search_end)
+{
+    if (!ix) return GENIE_E_INVALID;
+    ix->ev_search_begin = ev_search_begin;
+    ix->ev_search_end = ev_search_end;
+    return GENIE_OK;
+}
+
 const char *genie_strerror(int status)
 {
     switch (status) {

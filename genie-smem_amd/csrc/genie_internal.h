@@ -139,6 +139,8 @@ struct genie_index {
     int64_t blob_bytes = 0;
     int32_t num_cus = 0;
     int32_t opt_lut_probe = 0;       // GENIE_OPT_LUT_PROBE
+    void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel
+    void *ev_search_end = nullptr;
 };
 
 // kernels.hip

@@ -869,9 +869,11 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     int32_t *st = d_status ? d_status : ws.status;
     auto ka = match_stats_kernel<MODE, NS>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
                        fixed_len, ws.fwd, g.fwd_stride, ws.qp, st, g.leaf_in_lds, ix->opt_lut_probe);
     HIP_TRY(hipGetLastError());
+    if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     auto kb = traverse_kernel<MODE>;
     const int tb = 256;
     const int lds_b = tb * g.fwd_stride;
@@ -926,10 +928,12 @@ int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_
     }
     auto kern = find_smems_kernel<MODE>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
                        fixed_len, g.Lmax, min_len, d_counts, reinterpret_cast<int4 *>(d_slots), cap, d_status,
                        g.leaf_in_lds);
     HIP_TRY(hipGetLastError());
+    if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     return GENIE_OK;
 }
 

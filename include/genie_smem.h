@@ -183,6 +183,12 @@ int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t
 enum { GENIE_OPT_LUT_PROBE = 1 };
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
 
+/* Profiling hook: two hipEvent_t (as void*, created by the caller with timing enabled) that the next
+ * genie_find_smems calls record on their stream immediately before and after the dominant kernel of
+ * the path (the suffix-array search: match_stats_kernel, or find_smems_kernel for reads > 255 bp).
+ * Pass NULLs to stop.  Not thread-safe with concurrent launches on the same handle. */
+int genie_index_set_stage_events(genie_index *ix, void *ev_search_begin, void *ev_search_end);
+
 /* Launch geometry actually used by genie_find_smems for (mode, max read length): for reports. */
 int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
                       int32_t *lds_bytes);
