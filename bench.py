@@ -9,8 +9,8 @@ one rank per GPU.  Rank 0 builds the index and broadcasts its image ONCE over RC
 that ranks never communicate inside the timed region (reads are independent units, weak scaling:
 every rank processes its own batch of the same shape).
 
-A "step" = one pass of the hot path over one batch: the SMEM kernel over all reads of the batch
-plus the compaction of its output to CSR, with the reads already resident in HBM.
+A "step" = one pass of the hot path over one batch: ONE genie_find_smems_csr call (match statistics,
+traversal, offsets scan, interval search writing the CSR rows) with the reads already resident in HBM.
 Rank 0 prints ONE JSON line (schema in the task contract) with `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -118,12 +118,9 @@ def main():
     reads = torch.as_tensor(synth.reads_from_ref_fast(ref_codes, n_reads, cfg["L"], cfg["read_seed"] + rank)).to(device)
     L = cfg["L"]
     cap = L
-    counts = torch.empty(n_reads, dtype=torch.int32, device=device)
-    slots = torch.empty((n_reads, cap, 4), dtype=torch.int32, device=device)
     status = torch.empty(n_reads, dtype=torch.int32, device=device)
     offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=device)
     out = torch.empty((n_reads * 40, 4), dtype=torch.int32, device=device)      # CSR rows (>= 3x the mean count)
-    tmp = torch.empty(max(int(g._native.lib().genie_compact_tmp_bytes(n_reads)), 16), dtype=torch.uint8, device=device)
     ws_bytes = int(g._native.lib().genie_find_smems_workspace_bytes(n_reads, L))
     ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device)
 
@@ -149,12 +146,10 @@ def main():
         if i is not None:
             lib.genie_index_set_stage_events(ix._h, EV(ev_k[i][0]), EV(ev_k[i][1]))
             ev[i][0].record(stream)
-        g._native.check(lib.genie_find_smems(ix._h, mode_id, P(reads), None, n_reads, L, L, 1, P(counts), P(slots), cap,
-                                             P(status), P(ws), ws_bytes, sp), "genie_find_smems")
+        g._native.check(lib.genie_find_smems_csr(ix._h, mode_id, P(reads), None, n_reads, L, L, 1, P(offsets), P(out),
+                                                 out.shape[0], P(status), P(ws), ws_bytes, sp), "genie_find_smems_csr")
         if i is not None:
             ev[i][1].record(stream)
-        g._native.check(lib.genie_compact_smems(P(counts), P(slots), n_reads, cap, P(offsets), P(out), out.shape[0],
-                                                P(tmp), sp), "genie_compact_smems")
 
     for _ in range(args.warmup):
         step()
@@ -229,7 +224,7 @@ def main():
                                  "position, 12 B per probe); the kernel serves most of them from LDS (the P-mer directory "
                                  "replaces the first ~14 of 17 probe steps) and L2 (the index is cache-resident), so "
                                  "achieved can exceed the HBM peak; `traffic` is the measured HBM bytes per launch",
-                         "path": {"kernels": "match_stats + traverse + interval (one genie_find_smems call)",
+                         "path": {"kernels": "match_stats + traverse + offsets scan + interval->CSR (one genie_find_smems_csr call)",
                                   "ms_avg": path_ms_avg, "alg_bytes_per_read": bytes_path,
                                   "achieved": bytes_path * n_reads / (path_ms_avg * 1e-3) / 1e9,
                                   "share_of_step": path_ms_avg / (dt / args.steps * 1e3)}},

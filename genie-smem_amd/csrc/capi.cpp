@@ -229,6 +229,24 @@ int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads
                              d_status, d_workspace, workspace_bytes, stream);
 }
 
+int genie_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
+                         int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int64_t *d_offsets,
+                         int32_t *d_rows, int64_t out_cap_rows, int32_t *d_status, void *d_workspace,
+                         int64_t workspace_bytes, void *stream)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    if (N < 0 || stride < 0 || fixed_len < 0 || out_cap_rows < 0 || !d_offsets || (N > 0 && (!d_reads || !d_rows)))
+        return GENIE_E_INVALID;
+    if (mode < GENIE_MODE_BWA || mode > GENIE_MODE_RMI) return GENIE_E_INVALID;
+    if (fixed_len > 255) return GENIE_E_TOO_LONG;
+    if (mode != GENIE_MODE_BWA && ix->dev.K < 1) return GENIE_E_NO_LUT;
+    if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
+    if ((reinterpret_cast<uintptr_t>(d_rows) & 15) != 0) return GENIE_E_INVALID;
+    return launch_find_smems_csr(ix, mode, d_reads, d_lens, N, stride, fixed_len, min_len, d_offsets, d_rows, out_cap_rows,
+                                 d_status, d_workspace, workspace_bytes, stream);
+}
+
 int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len)
 {
     if (N < 0 || max_len < 0) return (int64_t)GENIE_E_INVALID;

@@ -847,26 +847,59 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
 }
 
 struct Workspace {
-    uint8_t *fwd;
+    uint8_t *fwd;        // N x fwd_stride bytes
     RefRec *qp;          // 2*ns records of 16 bytes per read
-    int32_t *status;
+    int32_t *status;     // used when the caller passes no status array
+    uint16_t *kj;        // N x kj_stride emitted (start | end << 8) pairs
+    int32_t *counts;     // used by the CSR entry point
+    uint8_t *scan_tmp;   // scratch of the offsets scan (CSR entry point)
 };
 
 inline int64_t ws_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+inline int kj_row(int max_len) { return (std::max(max_len, 1) + 7) & ~7; }       // entries per read (>= max SMEMs)
 
 inline int64_t workspace_bytes_for(int64_t N, int max_len)
 {
     if (max_len > 255) return 0;
     const int ns = std::max(1, (max_len + 63) / 64);
-    return ws_align(N * (int64_t)fwd_row_bytes(max_len)) + ws_align(N * (int64_t)(2 * ns) * 16) + ws_align(N * 4) + 256;
+    return ws_align(N * (int64_t)fwd_row_bytes(max_len)) + ws_align(N * (int64_t)(2 * ns) * 16) + ws_align(N * 4) +
+           ws_align(N * (int64_t)kj_row(max_len) * 2) + ws_align(N * 4) + ws_align(compact_tmp_bytes(N)) + 256;
 }
+
+inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, int max_len, Workspace *ws)
+{
+    if (!d_ws || ws_bytes < workspace_bytes_for(N, max_len) || (reinterpret_cast<uintptr_t>(d_ws) & 255) != 0)
+        return GENIE_E_CAPACITY;
+    const int ns = std::max(1, (max_len + 63) / 64);
+    uint8_t *p = reinterpret_cast<uint8_t *>(d_ws);
+    ws->fwd = p;
+    p += ws_align(N * (int64_t)fwd_row_bytes(max_len));
+    ws->qp = reinterpret_cast<RefRec *>(p);
+    p += ws_align(N * (int64_t)(2 * ns) * 16);
+    ws->status = reinterpret_cast<int32_t *>(p);
+    p += ws_align(N * 4);
+    ws->kj = reinterpret_cast<uint16_t *>(p);
+    p += ws_align(N * (int64_t)kj_row(max_len) * 2);
+    ws->counts = reinterpret_cast<int32_t *>(p);
+    p += ws_align(N * 4);
+    ws->scan_tmp = p;
+    return GENIE_OK;
+}
+
+struct CsrOut {
+    int64_t *offsets = nullptr;      // non-null => write CSR rows to `rows`, else slots
+    int32_t *rows = nullptr;
+    int64_t cap_rows = 0;
+};
 
 template <int MODE, int NS>
 int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
                  int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots, int32_t cap,
-                 int32_t *d_status, const Workspace &ws, hipStream_t s)
+                 int32_t *d_status, const Workspace &ws, const CsrOut &csr, hipStream_t s)
 {
     int32_t *st = d_status ? d_status : ws.status;
+    int32_t *cnt = d_counts ? d_counts : ws.counts;
+    const int kjs = kj_row(fixed_len);
     auto ka = match_stats_kernel<MODE, NS>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
@@ -879,10 +912,14 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     const int lds_b = tb * g.fwd_stride;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, 2 * NS, d_counts,
-                       reinterpret_cast<int4 *>(d_slots), cap, st);
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, 2 * NS, cnt, ws.kj, kjs,
+                       csr.offsets ? kjs : cap, st);
     HIP_TRY(hipGetLastError());
-    // K_C: intervals, 16 lanes per read, persistent blocks with the directory in LDS
+    if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
+        int rc = launch_compact(cnt, nullptr, N, kjs, csr.offsets, nullptr, 0, ws.scan_tmp, s);
+        if (rc) return rc;
+    }
+    // K_C: intervals + final rows, 16 lanes per read, persistent blocks with the directory in LDS
     const int lds_c = (ix->dev.dir_entries * 4 + 15) & ~15;
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
     int blocks_c = 160 * 1024 / lds_c;
@@ -890,9 +927,18 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     long long grid_c = (long long)cus * blocks_c;
     const long long need_c = (N + 63) / 64;
     if (grid_c > need_c) grid_c = need_c;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(interval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
-    hipLaunchKernelGGL(interval_kernel, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, d_counts,
-                       reinterpret_cast<int4 *>(d_slots), cap, ws.qp, 2 * NS);
+    if (csr.offsets) {
+        auto kc = interval_kernel<true>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
+        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, kjs, ws.qp,
+                           2 * NS, reinterpret_cast<int4 *>(csr.rows), 0, reinterpret_cast<const long long *>(csr.offsets),
+                           (long long)csr.cap_rows);
+    } else {
+        auto kc = interval_kernel<false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
+        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, kjs, ws.qp,
+                           2 * NS, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
+    }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -900,22 +946,16 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
 template <int MODE>
 int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
                      int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
-                     int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, hipStream_t s)
+                     int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, const CsrOut &csr, hipStream_t s)
 {
     if (g.ns > 0) {
-        if (!d_ws || ws_bytes < workspace_bytes_for(N, fixed_len) || (reinterpret_cast<uintptr_t>(d_ws) & 255) != 0)
-            return GENIE_E_CAPACITY;
         Workspace ws;
-        uint8_t *p = reinterpret_cast<uint8_t *>(d_ws);
-        ws.fwd = p;
-        p += ws_align(N * (int64_t)g.fwd_stride);
-        ws.qp = reinterpret_cast<RefRec *>(p);
-        p += ws_align(N * (int64_t)(2 * g.ns) * 16);
-        ws.status = reinterpret_cast<int32_t *>(p);
+        int rc = carve_workspace(d_ws, ws_bytes, N, fixed_len, &ws);
+        if (rc) return rc;
 #define GENIE_SHORT(NS_)                                                                                        \
     case NS_:                                                                                                   \
         return launch_short<MODE, NS_>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, \
-                                       cap, d_status, ws, s)
+                                       cap, d_status, ws, csr, s)
         switch (g.ns) {
             GENIE_SHORT(1);
             GENIE_SHORT(2);
@@ -926,6 +966,7 @@ int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_
         }
 #undef GENIE_SHORT
     }
+    if (csr.offsets) return GENIE_E_TOO_LONG;        // the fused CSR entry point covers the short-read pipeline
     auto kern = find_smems_kernel<MODE>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
@@ -965,11 +1006,10 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
 
 int64_t find_smems_workspace_bytes(int64_t N, int32_t max_len) { return workspace_bytes_for(N, max_len); }
 
-int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
-                      int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
-                      int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, void *stream)
+static int launch_find_any(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                           int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
+                           int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, const CsrOut &csr, void *stream)
 {
-    if (N == 0) return GENIE_OK;
     Geometry g;
     // with ragged lengths `fixed_len` carries the maximum length (host contract)
     int rc = plan_find_smems(ix, mode, fixed_len, N, &g);
@@ -978,15 +1018,40 @@ int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_read
     switch (mode) {
     case GENIE_MODE_BWA:
         return launch_find_mode<GENIE_MODE_BWA>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
-                                                cap, d_status, d_ws, ws_bytes, s);
+                                                cap, d_status, d_ws, ws_bytes, csr, s);
     case GENIE_MODE_LUT:
         return launch_find_mode<GENIE_MODE_LUT>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
-                                                cap, d_status, d_ws, ws_bytes, s);
+                                                cap, d_status, d_ws, ws_bytes, csr, s);
     case GENIE_MODE_RMI:
         return launch_find_mode<GENIE_MODE_RMI>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots,
-                                                cap, d_status, d_ws, ws_bytes, s);
+                                                cap, d_status, d_ws, ws_bytes, csr, s);
     }
     return GENIE_E_INVALID;
+}
+
+int launch_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                      int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
+                      int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, void *stream)
+{
+    if (N == 0) return GENIE_OK;
+    return launch_find_any(ix, mode, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, cap, d_status, d_ws,
+                           ws_bytes, CsrOut{}, stream);
+}
+
+int launch_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                          int32_t stride, int32_t fixed_len, int32_t min_len, int64_t *d_offsets, int32_t *d_rows,
+                          int64_t out_cap_rows, int32_t *d_status, void *d_ws, int64_t ws_bytes, void *stream)
+{
+    if (N == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, (hipStream_t)stream));
+        return GENIE_OK;
+    }
+    CsrOut csr;
+    csr.offsets = d_offsets;
+    csr.rows = d_rows;
+    csr.cap_rows = out_cap_rows;
+    return launch_find_any(ix, mode, d_reads, d_lens, N, stride, fixed_len, min_len, nullptr, nullptr, 0, d_status, d_ws,
+                           ws_bytes, csr, stream);
 }
 
 int launch_sa_interval(const genie_index *ix, const uint8_t *d_pats, const int32_t *d_lens, int64_t N, int32_t stride,

@@ -234,12 +234,42 @@ class GenieIndex:
                                                 out.shape[0], _ptr(tmp), st), "genie_compact_smems")
         return offsets, out
 
-    def find_smems(self, mode, reads, lens=None, min_len=1, cap=None):
-        """Batched SMEM discovery -> (offsets int64[N+1], smems int32[S,4] = (start,end,lo,hi), status)."""
-        counts, slots, status = self.find_smems_slots(mode, reads, lens, min_len, cap)
-        offsets, out = self.compact(counts, slots)
-        total = int(offsets[-1].item())
-        return offsets, out[:total], status
+    def find_smems(self, mode, reads, lens=None, min_len=1, cap=None, rows_hint=None):
+        """Batched SMEM discovery -> (offsets int64[N+1], smems int32[S,4] = (start,end,lo,hi), status).
+        Reads of at most 255 bases go through the fused CSR entry point (genie_find_smems_csr);
+        longer ones through the slotted kernel + compaction."""
+        self._need_device()
+        reads = self._as_dev(reads, torch.uint8)
+        if reads.dim() != 2:
+            raise ValueError("reads must be [N, stride]")
+        n_reads, stride = reads.shape
+        fixed = stride
+        if lens is not None:
+            lens = self._as_dev(lens, torch.int32)
+            fixed = int(lens.max().item()) if n_reads else 0
+            if fixed > stride or (n_reads and int(lens.min().item()) < 0):
+                raise ValueError("read length outside [0, stride]")
+        if fixed > 255 or cap is not None or n_reads == 0 or stride == 0:
+            counts, slots, status = self.find_smems_slots(mode, reads, lens, min_len, cap)
+            offsets, out = self.compact(counts, slots)
+            total = int(offsets[-1].item())
+            return offsets, out[:total], status
+        offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=self.device)
+        status = torch.empty(n_reads, dtype=torch.int32, device=self.device)
+        ws_bytes = int(N.lib().genie_find_smems_workspace_bytes(n_reads, fixed))
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=self.device)
+        cap_rows = int(rows_hint) if rows_hint else n_reads * max(8, fixed // 6)
+        while True:
+            rows = torch.empty((max(cap_rows, 1), 4), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                N.check(N.lib().genie_find_smems_csr(self._h, N.MODES[mode], _ptr(reads), _ptr(lens), n_reads, stride,
+                                                     fixed, int(min_len), _ptr(offsets), _ptr(rows), rows.shape[0],
+                                                     _ptr(status), _ptr(ws), ws_bytes, _stream(self.device)),
+                        "genie_find_smems_csr")
+            total = int(offsets[-1].item())
+            if total <= rows.shape[0]:
+                return offsets, rows[:total], status
+            cap_rows = total                      # capacity guess too small: rerun with the exact size
 
     def set_option(self, option, value):
         N.check(N.lib().genie_index_set_option(self._h, int(option), int(value)), "genie_index_set_option")

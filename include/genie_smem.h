@@ -169,6 +169,16 @@ int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads
                      int32_t *d_slots, int32_t cap, int32_t *d_status, void *d_workspace, int64_t workspace_bytes,
                      void *stream);
 
+/* Same discovery, CSR output in one call (reads of at most 255 bases; longer: GENIE_E_TOO_LONG, use
+ * genie_find_smems + genie_compact_smems): d_offsets[N+1] = exclusive prefix sum of the per-read SMEM
+ * counts, d_rows[4*t .. 4*t+3] = (start, end, lo, hi) of SMEM t, reads in input order, SMEMs in the
+ * reference's emission order.  Every row is written exactly once; rows beyond out_cap_rows are
+ * dropped (the caller compares d_offsets[N] with its capacity).  Flagged reads contribute no rows. */
+int genie_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
+                         int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int64_t *d_offsets,
+                         int32_t *d_rows, int64_t out_cap_rows, int32_t *d_status, void *d_workspace,
+                         int64_t workspace_bytes, void *stream);
+
 /* Compact the slotted output to CSR: d_offsets[N+1] (exclusive prefix sum of min(count,cap))
  * and d_out[total*4].  d_tmp: scratch of genie_compact_tmp_bytes(N) bytes. */
 int64_t genie_compact_tmp_bytes(int64_t N);
