@@ -54,6 +54,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// wave max in 6 DPP steps (row_shr 1,2,4,8, row_bcast 15/31), result read from lane 63: no LDS crossbar
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ------------------------------------------------------------------ packed windows
 // 32 bases starting at base offset `pos`: base j of the window sits in bits [62-2j, 63-2j].
 __device__ __forceinline__ uint64_t funnel(uint64_t w0, uint64_t w1, int sh /* 0..62, even */)
@@ -851,6 +864,7 @@ struct Workspace {
     RefRec *qp;          // 2*ns records of 16 bytes per read
     int32_t *status;     // used when the caller passes no status array
     uint16_t *kj;        // N x kj_stride emitted (start | end << 8) pairs
+    unsigned long long *hm;  // N x (ns+1): K-mer hit mask per 64 positions + longest match
     int32_t *counts;     // used by the CSR entry point
     uint8_t *scan_tmp;   // scratch of the offsets scan (CSR entry point)
 };
@@ -863,7 +877,8 @@ inline int64_t workspace_bytes_for(int64_t N, int max_len)
     if (max_len > 255) return 0;
     const int ns = std::max(1, (max_len + 63) / 64);
     return ws_align(N * (int64_t)fwd_row_bytes(max_len)) + ws_align(N * (int64_t)(2 * ns) * 16) + ws_align(N * 4) +
-           ws_align(N * (int64_t)kj_row(max_len) * 2) + ws_align(N * 4) + ws_align(compact_tmp_bytes(N)) + 256;
+           ws_align(N * (int64_t)kj_row(max_len) * 2) + ws_align(N * (int64_t)(ns + 1) * 8) + ws_align(N * 4) +
+           ws_align(compact_tmp_bytes(N)) + 256;
 }
 
 inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, int max_len, Workspace *ws)
@@ -880,6 +895,8 @@ inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, int max_len,
     p += ws_align(N * 4);
     ws->kj = reinterpret_cast<uint16_t *>(p);
     p += ws_align(N * (int64_t)kj_row(max_len) * 2);
+    ws->hm = reinterpret_cast<unsigned long long *>(p);
+    p += ws_align(N * (int64_t)(ns + 1) * 8);
     ws->counts = reinterpret_cast<int32_t *>(p);
     p += ws_align(N * 4);
     ws->scan_tmp = p;
@@ -904,7 +921,7 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
-                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, st, g.leaf_in_lds, ix->opt_lut_probe);
+                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, ws.hm, st, g.leaf_in_lds, ix->opt_lut_probe);
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     auto kb = traverse_kernel<MODE>;
@@ -912,7 +929,7 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     const int lds_b = tb * g.fwd_stride;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, 2 * NS, cnt, ws.kj, kjs,
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, 2 * NS, ws.hm, NS + 1, cnt, ws.kj, kjs,
                        csr.offsets ? kjs : cap, st);
     HIP_TRY(hipGetLastError());
     if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
