@@ -187,6 +187,24 @@ __device__ __forceinline__ Cmp cmp_rec(const DevIndex &ix, const Q qp, int a, in
     return {l, less};
 }
 
+// Probe position inside the open row range [lo, hi).  Rows of a directory bucket share their first P
+// bases, and their inline keys (the next 32 bases) are close to uniformly distributed, so the position
+// of the pattern's key `xq32` between the key bounds already seen (`vlo`, `vhi`: top 32 bits) predicts
+// the row -- a learned-index step at bucket scale.  Every other step is a plain bisection, which keeps
+// the worst case logarithmic on repeat-rich references (many equal keys).  Only the CHOICE of the
+// probe is heuristic: correctness rests on the lo/hi updates of the caller.
+__device__ __forceinline__ int pick_probe(int lo, int hi, uint32_t xq32, uint32_t vlo, uint32_t vhi, int step)
+{
+    const int n = hi - lo;
+    if ((step & 1) || n <= 2 || vhi <= vlo) return (lo + hi) >> 1;
+    if (xq32 <= vlo) return lo;
+    if (xq32 >= vhi) return hi - 1;
+    const float f = (float)(xq32 - vlo) / (float)(vhi - vlo);
+    int mid = lo + (int)(f * (float)n);
+    mid = mid < lo ? lo : (mid > hi - 1 ? hi - 1 : mid);
+    return mid;
+}
+
 __device__ __forceinline__ SaRec load_rec(const SaRec *sa, int row)
 {
     const int4 v = *reinterpret_cast<const int4 *>(sa + row);          // one 16-byte load
@@ -310,12 +328,16 @@ __device__ __forceinline__ int ms_search(const DevIndex &ix, const Q qp, int a, 
     int best = skip;
     const bool use_key = skip == ix.P;
     const uint64_t xq = qp.win(a + ix.P);
+    uint32_t vlo = 0, vhi = 0xFFFFFFFFu;
+    int step = use_key ? 0 : 1;
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = use_key ? pick_probe(lo, hi, (uint32_t)(xq >> 32), vlo, vhi, step) : (lo + hi) >> 1;
+        step++;
         const SaRec rec = load_rec(ix.sa, mid);
         const Cmp c = use_key ? cmp_rec(ix, qp, a, m, rec, xq) : cmp_suffix(ix, qp, a, m, rec.s, skip);
         best = c.l > best ? c.l : best;
-        if (c.less) lo = mid + 1; else hi = mid;
+        if (c.less) { lo = mid + 1; vlo = (uint32_t)(rec.key >> 32); }
+        else { hi = mid; vhi = (uint32_t)(rec.key >> 32); }
     }
     return best;
 }
@@ -360,15 +382,24 @@ __device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *
     const int hi = (int)dir_ub(ix, dir, b, P);
     const uint64_t xq = qp.win(a + P);
     int h = hi;
+    uint32_t vlo = 0, vhi = 0xFFFFFFFFu;
+    int step = 0;
     while (lo < h) {                                    // first row whose suffix is not < pattern
-        const int mid = (lo + h) >> 1;
-        if (cmp_rec(ix, qp, a, m, load_rec(ix.sa, mid), xq).less) lo = mid + 1; else h = mid;
+        const int mid = pick_probe(lo, h, (uint32_t)(xq >> 32), vlo, vhi, step++);
+        const SaRec rec = load_rec(ix.sa, mid);
+        if (cmp_rec(ix, qp, a, m, rec, xq).less) { lo = mid + 1; vlo = (uint32_t)(rec.key >> 32); }
+        else { h = mid; vhi = (uint32_t)(rec.key >> 32); }
     }
     const int first = lo;
     h = hi;
-    while (lo < h) {                                    // first row that no longer has it as prefix
-        const int mid = (lo + h) >> 1;
-        if (cmp_rec(ix, qp, a, m, load_rec(ix.sa, mid), xq).l >= m) lo = mid + 1; else h = mid;
+    // first row that no longer has the pattern as prefix: matching rows are adjacent to `first`
+    // (usually one or two), so gallop up from it and bisect the last gap
+    int stepw = 1;                                      // 0 once a non-matching row bounds the range: bisect
+    while (lo < h) {
+        int mid = stepw ? lo + stepw - 1 : (lo + h) >> 1;
+        if (mid >= h) mid = (lo + h) >> 1;
+        if (cmp_rec(ix, qp, a, m, load_rec(ix.sa, mid), xq).l >= m) { lo = mid + 1; stepw = stepw && stepw < (1 << 20) ? stepw << 1 : stepw; }
+        else { h = mid; stepw = 0; }
     }
     return first < lo ? make_int2(first, lo - 1) : make_int2(-1, -1);
 }

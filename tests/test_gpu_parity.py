@@ -300,6 +300,41 @@ def test_absent_base_is_flagged(pkg):
         pkg.SMEM(m, lut_size=2).get_SMEMS("ACAGAC", 1)
 
 
+# ------------------------------------------------------------------ 1 Mb reference (BASELINE configs 3-4 shape)
+def test_one_megabase_reference(pkg, oracle_mod):
+    """REF_1M (seed 1 000 000), K = 15, natively trained RMI [1000]: the three modes against the CPU
+    oracle on from-ref and random reads, plus exact-match patterns."""
+    from genie_smem_amd import synth as B
+    ref = B.synth_ref(1_000_000, 1_000_000)
+    m = pkg.ExactMatch("REF_1M.fa")
+    m.set_reference(G.codes_to_str(ref))
+    r = pkg.RMI_LUT([1000], 15, "REF_1M.fa", matcher=m)
+    r.train_RMI()
+    ix = r._index()
+    o = oracle_mod.Oracle(ref, 15)
+    coefs, icpts = r.rmi.coefficients()
+    o.set_rmi([1000], coefs, icpts)
+    for kind, rd in (("fromref", B.reads_from_ref(ref, 3000, 150, 1004)), ("random", B.reads_random(1000, 150, 1005))):
+        for algo in ("bwa", "lut", "rmi"):
+            offsets, smems, st = ix.find_smems(algo, rd)
+            assert int(st.abs().sum().item()) == 0
+            rows = _rows_per_read(offsets, smems)
+            counts, want = o.find_smems_batch(algo, rd, nthreads=16)
+            for i in range(len(rd)):
+                assert rows[i].tolist() == want[i, :counts[i]].tolist(), (kind, algo, i)
+    rng = np.random.default_rng(9)
+    pats = np.zeros((2000, 60), np.uint8)
+    lens = rng.integers(1, 61, 2000).astype(np.int32)
+    for i in range(2000):
+        p0 = int(rng.integers(0, len(ref) - 60))
+        pats[i, :lens[i]] = ref[p0:p0 + lens[i]]
+        if i % 3 == 0:
+            pats[i, lens[i] - 1] = (pats[i, lens[i] - 1] + 1) % 4
+    got = ix.sa_interval(pats, lens).cpu().numpy()
+    for i in range(2000):
+        assert tuple(got[i]) == o.back_prop(pats[i, :lens[i]]), i
+
+
 # ------------------------------------------------------------------ full-size properties (config 2/3 shape)
 def test_full_size_properties(pkg, oracle_mod):
     """1M x 150 bp reads on the 100 kb reference (BASELINE config 1/2 shape).  Size-independent
