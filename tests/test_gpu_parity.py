@@ -348,7 +348,11 @@ def test_full_size_properties(pkg, oracle_mod):
     d, _ = G.load("syn100k_K15")
     ix = _index_for(pkg, "syn100k_K15", "rmi")
     n_reads = 1_000_000
-    rd_np = B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, 1002)
+    import os
+    seed = int(os.environ.get("GENIE_TEST_SEED", "1002"))            # vary to soak-test the full-occupancy guard
+    rd_np = B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, seed)
+    if seed % 2:                                                     # odd seeds: a third of the batch uniform-random
+        rd_np[::3] = B.reads_random((n_reads + 2) // 3, 150, seed + 1)
     rd = torch.as_tensor(rd_np).cuda()
     res = {}
     for rep in range(2):
