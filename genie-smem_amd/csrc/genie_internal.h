@@ -7,10 +7,14 @@
 
 #include "genie_smem.h"
 
+#ifndef __HIPCC__
+struct uint2 { unsigned int x, y; };
+#endif
+
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -73,6 +77,10 @@ struct BlobHeader {
     int32_t rmi_scale[GENIE_MAX_RMI_LEVELS];
     int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1];
     uint32_t padtail[8];  // padtail[l] = code(last l bases) << 2(P-l) for l < P, kNoTail if l > n
+    int64_t off_dir2;     // uint32 pairs [4^P2]: exact row range [lb, ub) of every P2-mer (lb == ub: absent)
+    int64_t dir2_entries;
+    int32_t P2;           // 0 = no second-level table
+    int32_t pad2;
 };
 // The serialized header occupies GENIE_HEADER_BYTES; the struct is copied into its front.
 static_assert(sizeof(BlobHeader) <= GENIE_HEADER_BYTES, "header size");
@@ -84,6 +92,7 @@ struct DevIndex {
     const uint32_t *dir;
     const LutSlot *lut;
     const RmiModel *rmi;
+    const uint2 *dir2;     // second-level range table (global, L2-resident), or null
     int32_t n;
     int32_t K;
     int32_t P;
@@ -93,6 +102,7 @@ struct DevIndex {
     int32_t rmi_scale[GENIE_MAX_RMI_LEVELS];
     int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1];
     uint32_t padtail[8];
+    int32_t P2;
 };
 
 inline uint32_t lut_hash(uint32_t code, uint32_t slots)
@@ -109,6 +119,8 @@ struct HostIndex {
     std::vector<int32_t> sa1;            // reference convention (1-based), for the host API
     std::vector<RefRec> ref;
     std::vector<uint32_t> dir;
+    int32_t P2 = 0;
+    std::vector<uint32_t> dir2;          // 2 x 4^P2: lb, ub interleaved
     std::vector<uint32_t> lut_code;      // sorted distinct K-mers
     std::vector<int32_t> lut_lo, lut_hi;
     std::vector<LutSlot> lut_slots;

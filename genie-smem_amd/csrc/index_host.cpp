@@ -81,6 +81,13 @@ inline uint32_t code_at(const uint8_t *codes, int64_t s, int len)
     return c;
 }
 
+inline uint64_t code_at64(const uint8_t *codes, int64_t s, int len)
+{
+    uint64_t c = 0;
+    for (int j = 0; j < len; j++) c = (c << 2) | codes[s + j];
+    return c;
+}
+
 // Is suffix a (0-based start) lexicographically smaller than suffix b?  ('$' smallest)
 bool suffix_less(const uint8_t *codes, int64_t n, int64_t a, int64_t b)
 {
@@ -158,6 +165,24 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
             else h->padtail[l] = kNoTail;
         }
 
+        // Second-level range table: for every P2-mer the exact rows [lb, ub) whose suffix starts with it
+        // (rows sharing a prefix are contiguous).  P2 = smallest with 4^P2 >= n/2, i.e. <= 2 rows per
+        // entry on average; skipped for references too small to need it.
+        if (n >= 65536) {
+            int P2 = P + 1;
+            while (P2 < 12 && ((int64_t)1 << (2 * P2)) < n / 2) P2++;
+            h->P2 = P2;
+            const int64_t nb2 = (int64_t)1 << (2 * P2);
+            h->dir2.assign((size_t)(2 * nb2), 0);
+            for (int64_t r = 0; r < rows; r++) {
+                const int64_t s = h->sa0[(size_t)r];
+                if (n - s < P2) continue;
+                const uint64_t c = code_at64(codes, s, P2);
+                if (h->dir2[(size_t)(2 * c)] == h->dir2[(size_t)(2 * c + 1)]) h->dir2[(size_t)(2 * c)] = (uint32_t)r;
+                h->dir2[(size_t)(2 * c + 1)] = (uint32_t)(r + 1);
+            }
+        }
+
         // K-mer table (LUT.generate_lut): rows sharing a K-mer prefix are contiguous in the SA.
         if (K > 0 && n >= K) {
             bool have = false;
@@ -211,6 +236,8 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->lut_slots = (int64_t)h.lut_slots.size();
     hdr->lut_keys = (int64_t)h.lut_code.size();
     hdr->rmi_models = (int64_t)h.rmi.size();
+    hdr->P2 = h.P2;
+    hdr->dir2_entries = (int64_t)h.dir2.size() / 2;
     hdr->nlev = h.nlev;
     for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
         hdr->rmi_size[l] = h.rmi_size[l];
@@ -229,6 +256,8 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     off = align_up(off + (int64_t)h.lut_slots.size() * (int64_t)sizeof(LutSlot));
     hdr->off_rmi = off;
     off = align_up(off + (int64_t)std::max<size_t>(h.rmi.size(), 1) * (int64_t)sizeof(RmiModel));
+    hdr->off_dir2 = off;
+    off = align_up(off + (int64_t)std::max<size_t>(h.dir2.size(), 2) * 4);
     hdr->total_bytes = off;
 }
 
@@ -245,6 +274,7 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     memcpy(p + hdr.off_dir, h.dir.data(), h.dir.size() * 4);
     memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
     if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
+    if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * 4);
     return GENIE_OK;
 }
 
@@ -254,6 +284,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
         return GENIE_E_BAD_BLOB;
     if (bytes < hdr.total_bytes || hdr.P < 1 || hdr.P > GENIE_MAX_DIR_BITS || hdr.n < 1) return GENIE_E_BAD_BLOB;
     if (hdr.dir_entries != ((int64_t)1 << (2 * hdr.P)) + 1) return GENIE_E_BAD_BLOB;
+    if (hdr.P2 != 0 && (hdr.P2 <= hdr.P || hdr.P2 > 12 || hdr.dir2_entries != ((int64_t)1 << (2 * hdr.P2)))) return GENIE_E_BAD_BLOB;
     if ((reinterpret_cast<uintptr_t>(d_blob) & 15) != 0) return GENIE_E_INVALID;
     const uint8_t *p = (const uint8_t *)d_blob;
     memset(out, 0, sizeof(*out));
@@ -262,6 +293,8 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->dir = (const uint32_t *)(p + hdr.off_dir);
     out->lut = (const LutSlot *)(p + hdr.off_lut);
     out->rmi = (const RmiModel *)(p + hdr.off_rmi);
+    out->dir2 = hdr.P2 > 0 ? (const uint2 *)(p + hdr.off_dir2) : nullptr;
+    out->P2 = hdr.P2;
     out->n = (int32_t)hdr.n;
     out->K = hdr.K;
     out->P = hdr.P;

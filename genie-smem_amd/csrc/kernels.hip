@@ -352,8 +352,12 @@ __device__ __forceinline__ int ms_generic(const DevIndex &ix, const uint32_t *di
     int t = m;
     if (m >= P) {
         const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
-        const int lo = (int)dir[b];                                   // == dir_lb(b, P)
-        const int hi = (int)dir_ub(ix, dir, b, P);
+        int lo = (int)dir[b];                                         // == dir_lb(b, P)
+        int hi = (int)dir_ub(ix, dir, b, P);
+        if (lo < hi && ix.P2 && m >= ix.P2) {                         // refine with the second-level table
+            const uint2 pr = ix.dir2[(uint32_t)(w >> (64 - 2 * ix.P2))];
+            if (pr.x < pr.y) { lo = (int)pr.x; hi = (int)pr.y; }
+        }
         if (lo < hi) return ms_search(ix, qp, a, m, lo, hi, P);
         t = P - 1;
     }
@@ -379,7 +383,13 @@ __device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *
     }
     const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
     int lo = (int)dir[b];
-    const int hi = (int)dir_ub(ix, dir, b, P);
+    int hi = (int)dir_ub(ix, dir, b, P);
+    if (ix.P2 && m >= ix.P2) {                         // second-level table: exact rows of the first P2 bases
+        const uint2 pr = ix.dir2[(uint32_t)(w >> (64 - 2 * ix.P2))];
+        if (pr.x >= pr.y) return make_int2(-1, -1);
+        lo = (int)pr.x;
+        hi = (int)pr.y;
+    }
     const uint64_t xq = qp.win(a + P);
     int h = hi;
     uint32_t vlo = 0, vhi = 0xFFFFFFFFu;

@@ -117,7 +117,7 @@ def test_reference_checked_in_fixtures(pkg):
 
 
 # ------------------------------------------------------------------ image + prefix directory
-HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8I")
+HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqii")
 
 
 def _parse(img):
@@ -125,7 +125,8 @@ def _parse(img):
     keys = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
             "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
     h = dict(zip(keys, f[:18]))
-    h["padtail"] = list(f[-8:])
+    h["padtail"] = list(f[-12:-4])
+    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-4], f[-3], f[-2]
     return h
 
 
@@ -227,3 +228,35 @@ def test_rmi_fit_is_a_usable_model(pkg):
     # scalar API shape: array of one float64, like the reference's rmi_predict
     q = G.codes_to_str(d["ref_codes"][100:108])
     assert r.rmi_predict(q).shape == (1,)
+
+
+def test_second_level_range_table(pkg):
+    """dir2[b] = exact [lb, ub) rows of every P2-mer b (lb == ub: absent), checked against the suffix array."""
+    d, _ = G.load("syn100k_K15")
+    ref = d["ref_codes"]
+    ix = pkg.GenieIndex.build(ref, 15)
+    img = ix.serialize().numpy()
+    h = _parse(img)
+    P2 = h["P2"]
+    assert P2 == 8 and h["dir2_entries"] == 4 ** P2
+    pairs = np.frombuffer(bytes(img[h["off_dir2"]:h["off_dir2"] + 8 * h["dir2_entries"]]), np.uint32).reshape(-1, 2)
+    sa0 = ix.suffix_array().astype(np.int64) - 1
+    n = len(ref)
+    full = sa0 + P2 <= n
+    codes = np.zeros(len(sa0), np.int64)
+    for j in range(P2):
+        codes = (codes << 2) | np.where(full, ref[np.minimum(sa0 + j, n - 1)], 0)
+    rows = np.nonzero(full)[0]
+    c = codes[rows]
+    assert (np.diff(c) >= 0).all()                                  # rows with a full P2-mer are sorted by it
+    first = np.full(4 ** P2, -1, np.int64)
+    last = np.full(4 ** P2, -1, np.int64)
+    first[c[::-1]] = rows[::-1]
+    last[c] = rows
+    present = first >= 0
+    assert (pairs[present, 0] == first[present]).all() and (pairs[present, 1] == last[present] + 1).all()
+    assert (pairs[~present, 0] >= pairs[~present, 1]).all()
+    # contiguity: the rows between first and last all carry the same P2-mer
+    assert (last[present] - first[present] + 1 == np.bincount(c, minlength=4 ** P2)[present]).all()
+    # small references carry no second-level table
+    assert _parse(pkg.GenieIndex.build(ref[:5000], 8).serialize().numpy())["P2"] == 0
