@@ -207,7 +207,10 @@ __device__ __forceinline__ int pick_probe(int lo, int hi, uint32_t xq32, uint32_
 
 __device__ __forceinline__ SaRec load_rec(const SaRec *sa, int row)
 {
-    const int4 v = *reinterpret_cast<const int4 *>(sa + row);          // one 16-byte load
+    int4 v = *reinterpret_cast<const int4 *>(sa + row);                // one 16-byte load
+    // all four dwords are declared live: otherwise hipcc narrows the access to a dword + a dwordx2
+    // load (the pad word is unused), i.e. TWO vector-memory instructions per probe
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     SaRec r;
     r.s = v.x;
     r.pad = 0;
