@@ -167,6 +167,20 @@ def test_dropin_smem_api(pkg):
         s2.get_smems_lut("A")                             # shorter than K
 
 
+def test_score_lut_driver(pkg, tmp_path):
+    """The reference's benchmark driver (SMEM.py:508-539) on the drop-in classes, paper-sized queries."""
+    import random
+    from genie_smem_amd.score import score_LUT
+    d, _ = G.load("syn10k_K8")
+    data = tmp_path / "data"
+    data.mkdir()
+    with open(data / "syn10k.fa", "w") as fh:
+        fh.write(">syn\n" + G.codes_to_str(d["ref_codes"]) + "\n")
+    random.seed(3)
+    res = score_LUT(4, "syn10k.fa", query_size=600, data_dir=str(data), lut_size=8, batched=True)
+    assert len(res) == 6 and all(t > 0 for t in res)
+
+
 # ------------------------------------------------------------------ A6 / A8: seeds
 def test_lut_seed_lookup(pkg):
     ds = "syn100k_K15"
