@@ -83,11 +83,15 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--mode", default=None, choices=["bwa", "lut", "rmi"])
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step (default: the config's)")
+    ap.add_argument("--read-len", type=int, default=None, help="off-config read length (sweeps only; named in config.workload)")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
+    if args.read_len and args.read_len != cfg["L"]:
+        cfg["L"] = args.read_len
+        cfg["name"] += f" [read_len={args.read_len}: off-config sweep point]"
     mode = args.mode or cfg["mode"]
     n_reads = args.reads or cfg["reads"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,7 +124,7 @@ def main():
     cap = L
     status = torch.empty(n_reads, dtype=torch.int32, device=device)
     offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=device)
-    out = torch.empty((n_reads * 40, 4), dtype=torch.int32, device=device)      # CSR rows (>= 3x the mean count)
+    out = torch.empty((n_reads * max(40, L // 3), 4), dtype=torch.int32, device=device)      # CSR rows (>= 3x the mean count)
     ws_bytes = int(g._native.lib().genie_find_smems_workspace_bytes(n_reads, L))
     ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device)
 
@@ -190,7 +194,7 @@ def main():
         bytes_path = bytes_search + 16.0 * smems_per_read
         achieved = bytes_search * n_reads / (kern_ms_avg * 1e-3) / 1e9
         launch = ix.launch_info(mode, L)
-        ns = (L + 63) // 64
+        ns = min(4, (L + 63) // 64)
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
@@ -216,7 +220,7 @@ def main():
                        "parallelism": f"query-sharded x{world}, index replicated (one RCCL broadcast)",
                        "smems_per_read": round(smems_per_read, 3), "launch": launch,
                        "index_build_plus_broadcast_s": round(t_build, 3)},
-            "roofline": {"bound": "hbm", "kernel": f"match_stats_kernel<{mode_id}, {ns}>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": f"match_stats_kernel<{mode_id}, {ns}, {'true' if L > 255 else 'false'}>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_read": bytes_search, "kernel_ms_avg": kern_ms_avg,
                          "kernel_ms_min": float(np.min(kern_ms)),

@@ -239,7 +239,7 @@ int genie_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_r
     if (N < 0 || stride < 0 || fixed_len < 0 || out_cap_rows < 0 || !d_offsets || (N > 0 && (!d_reads || !d_rows)))
         return GENIE_E_INVALID;
     if (mode < GENIE_MODE_BWA || mode > GENIE_MODE_RMI) return GENIE_E_INVALID;
-    if (fixed_len > 255) return GENIE_E_TOO_LONG;
+    if (fixed_len > GENIE_MAX_READ_LEN) return GENIE_E_TOO_LONG;
     if (mode != GENIE_MODE_BWA && ix->dev.K < 1) return GENIE_E_NO_LUT;
     if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
     if ((reinterpret_cast<uintptr_t>(d_rows) & 15) != 0) return GENIE_E_INVALID;

@@ -1,18 +1,11 @@
-// kernels.hip -- gfx950 (MI355X, wave64) kernels of the batched SMEM finder.
+// kernels.hip -- gfx950 (MI355X, wave64) kernels of the batched SMEM finder and their launch code.
 //
-// One wavefront per read.  Per read:
-//   phase 0  the read's bases are loaded coalesced, validated and packed 2 bits/base into LDS;
-//   phase 1  lane-parallel *matching statistics*: lane a computes fwd[a] = end of the longest
-//            prefix of read[a:] that occurs in the reference.  The seed is mode dependent --
-//            P-mer prefix directory (LDS) for BWA, K-mer hash table for LUT, RMI prediction
-//            (leaf coefficients in LDS) + last-mile search for RMI -- and is followed by a
-//            bounded binary search over suffix-array rows comparing 32 bases per 16-byte load
-//            of the packed reference (XOR + clz);
-//   phase 2  the reference's greedy traversal (get_SMEMS / get_smems_lut / get_smems_rmi) runs
-//            as a wave-uniform state machine over fwd[]; backward extension is a ballot-free
-//            lane-parallel max-reduction thanks to fwd[] being non-decreasing;
-//   phase 3  lane-parallel SA-interval search for every emitted SMEM and a 16-byte store of
-//            (start, end, lo, hi).
+// Device building blocks (this file): packed 32-base windows, the P-mer prefix directory with its
+// exact tail corrections, suffix comparison on inline-key suffix-array records, interval search,
+// K-mer hash table probe, RMI prediction + last-mile search.
+// The read pipeline K_A (match statistics, one wave per read) -> K_B (traversal, one lane per read)
+// -> K_C (intervals, one lane per SMEM) lives in short_read_kernel.inc; the single-step kernels
+// (batched exact match, seed lookup) and the offsets scan / compaction are below.
 // Pure integer / indexing work (one fp64 multiply-add per RMI level); no MFMA.
 //
 // The traversal is the *reduced form* of the reference's code; the
@@ -42,16 +35,6 @@ __device__ __forceinline__ void wave_lds_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, off, kWave);
-        v = o > v ? o : v;
-    }
-    return v;
 }
 
 // wave max in 6 DPP steps (row_shr 1,2,4,8, row_bcast 15/31), result read from lane 63: no LDS crossbar
@@ -322,55 +305,7 @@ __device__ __forceinline__ bool rmi_lookup(const DevIndex &ix, const RmiModel *l
     return true;
 }
 
-// ------------------------------------------------------------------ matching statistics
-// Longest prefix of q[a:L) that occurs in the reference (its length), by bounded binary search
-// over the SA rows [lo, hi) that all share the first `skip` bases with the pattern.
-template <class Q>
-__device__ __forceinline__ int ms_search(const DevIndex &ix, const Q qp, int a, int m, int lo, int hi, int skip)
-{
-    int best = skip;
-    const bool use_key = skip == ix.P;
-    const uint64_t xq = qp.win(a + ix.P);
-    uint32_t vlo = 0, vhi = 0xFFFFFFFFu;
-    int step = use_key ? 0 : 1;
-    while (lo < hi) {
-        const int mid = use_key ? pick_probe(lo, hi, (uint32_t)(xq >> 32), vlo, vhi, step) : (lo + hi) >> 1;
-        step++;
-        const SaRec rec = load_rec(ix.sa, mid);
-        const Cmp c = use_key ? cmp_rec(ix, qp, a, m, rec, xq) : cmp_suffix(ix, qp, a, m, rec.s, skip);
-        best = c.l > best ? c.l : best;
-        if (c.less) { lo = mid + 1; vlo = (uint32_t)(rec.key >> 32); }
-        else { hi = mid; vhi = (uint32_t)(rec.key >> 32); }
-    }
-    return best;
-}
-
-// Generic path: P-mer directory bucket, then ms_search; shorter than P bases => directory only.
-template <class Q>
-__device__ __forceinline__ int ms_generic(const DevIndex &ix, const uint32_t *dir, const Q qp, int a, int L)
-{
-    const int m = L - a;
-    const int P = ix.P;
-    const uint64_t w = qp.win(a);
-    int t = m;
-    if (m >= P) {
-        const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
-        int lo = (int)dir[b];                                         // == dir_lb(b, P)
-        int hi = (int)dir_ub(ix, dir, b, P);
-        if (lo < hi && ix.P2 && m >= ix.P2) {                         // refine with the second-level table
-            const uint2 pr = ix.dir2[(uint32_t)(w >> (64 - 2 * ix.P2))];
-            if (pr.x < pr.y) { lo = (int)pr.x; hi = (int)pr.y; }
-        }
-        if (lo < hi) return ms_search(ix, qp, a, m, lo, hi, P);
-        t = P - 1;
-    }
-    for (; t >= 1; --t) {
-        const uint32_t code = (uint32_t)(w >> (64 - 2 * t));
-        if (dir_lb(ix, dir, code, t) < dir_ub(ix, dir, code, t)) return t;
-    }
-    return 0;
-}
-
+// ------------------------------------------------------------------ interval search
 // Inclusive SA interval of q[a : a+m) (== ExactMatch.exact_match_back_prop of that substring);
 // (-1,-1) if absent, (0,n) for the empty pattern.
 template <class Q>
@@ -417,34 +352,28 @@ __device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *
     return first < lo ? make_int2(first, lo - 1) : make_int2(-1, -1);
 }
 
-// ------------------------------------------------------------------ per-wave scratch in LDS
+// ------------------------------------------------------------------ per-wave scratch in LDS (K1)
 struct WaveScratch {
-    uint64_t *qp;      // packed read, (Lmax+31)/32 + 2 words, zero padded
-    uint16_t *fwd;     // fwd[a], a in [0, L]
-    uint32_t *emit;    // emitted SMEMs: start | end << 16   (aliases the raw code bytes of phase 0)
+    uint64_t *qp;      // packed pattern, (Lmax+31)/32 + 2 words, zero padded
+    uint8_t *raw;      // raw codes while packing
 };
 
 __host__ __device__ inline int scratch_qp_bytes(int Lmax) { return (((Lmax + 31) / 32 + 2) * 8 + 15) & ~15; }
-__host__ __device__ inline int scratch_fwd_bytes(int Lmax) { return ((Lmax + 2) * 2 + 15) & ~15; }
-__host__ __device__ inline int scratch_emit_bytes(int Lmax) { return (Lmax * 4 + 15) & ~15; }
-__host__ __device__ inline int scratch_bytes(int Lmax)
-{
-    return scratch_qp_bytes(Lmax) + scratch_fwd_bytes(Lmax) + scratch_emit_bytes(Lmax);
-}
+__host__ __device__ inline int scratch_raw_bytes(int Lmax) { return (Lmax + 15) & ~15; }
+__host__ __device__ inline int scratch_bytes(int Lmax) { return scratch_qp_bytes(Lmax) + scratch_raw_bytes(Lmax); }
 
 __device__ __forceinline__ WaveScratch carve(uint8_t *base, int Lmax)
 {
     WaveScratch s;
     s.qp = reinterpret_cast<uint64_t *>(base);
-    s.fwd = reinterpret_cast<uint16_t *>(base + scratch_qp_bytes(Lmax));
-    s.emit = reinterpret_cast<uint32_t *>(base + scratch_qp_bytes(Lmax) + scratch_fwd_bytes(Lmax));
+    s.raw = base + scratch_qp_bytes(Lmax);
     return s;
 }
 
-// Phase 0: coalesced byte loads, validation, 2-bit packing.  Returns false on a code > 3.
+// coalesced byte loads, validation, 2-bit packing.  Returns false on a code > 3.
 __device__ __forceinline__ bool load_and_pack(const uint8_t *src, int L, int Lmax, const WaveScratch &ws, int lane)
 {
-    uint8_t *raw = reinterpret_cast<uint8_t *>(ws.emit);
+    uint8_t *raw = ws.raw;
     bool bad = false;
     for (int i = lane; i < L; i += kWave) {
         const uint8_t c = src[i];
@@ -462,249 +391,6 @@ __device__ __forceinline__ bool load_and_pack(const uint8_t *src, int L, int Lma
     }
     wave_lds_fence();
     return !__any(bad);
-}
-
-// ------------------------------------------------------------------ traversal (wave-uniform)
-struct Cand {
-    int len, k, j;
-};
-
-// SMEM.backward_extension (SMEM.py:389-423) for forward matches whose right ends are the
-// contiguous range [jmin, jmax] from `start`: for every j the leftmost k with q[k:j) present;
-// longest wins, ties to the smallest j (strict `>` in ascending key order, :413); finally the
-// longest forward match if strictly longer (:418-421).  fwd[] is non-decreasing, so
-// k(j) = min{k : fwd[k] >= j} and the best over j equals max_k (min(fwd[k], jmax) - k) over
-// k < start with fwd[k] >= jmin -- one lane per k and a wave max.  M = longest match in the read
-// bounds how far left k can be.
-__device__ __forceinline__ Cand back_ext(const uint16_t *fwd, int start, int jmin, int jmax, int M, int lane)
-{
-    uint32_t best = 0;
-    int klo = jmin - M;
-    klo = klo < 0 ? 0 : klo;
-    for (int k0 = klo; k0 < start; k0 += kWave) {
-        const int k = k0 + lane;
-        uint32_t key = 0;
-        if (k < start) {
-            const int f = fwd[k];
-            if (f >= jmin) {
-                const int j = f < jmax ? f : jmax;
-                key = ((uint32_t)(j - k) << 16) | (uint32_t)(0xFFFF - j);
-            }
-        }
-        best = key > best ? key : best;
-    }
-    best = rflu(wave_max_u32(best));
-    Cand c;
-    c.len = (int)(best >> 16);
-    c.j = 0xFFFF - (int)(best & 0xFFFF);
-    c.k = c.j - c.len;
-    if (jmax - start > c.len) { c.len = jmax - start; c.k = start; c.j = jmax; }
-    return c;
-}
-
-// SMEM.check_sequential on the position lists of the K-mers at read offsets c (current frame)
-// and pc (previous frame) (SMEM.py:75, 196-202 / 262-265): is there an occurrence p of the
-// current K-mer with the previous K-mer at p+1?  For adjacent frames (pc == c+1) this is
-// "the (K+1)-mer q[c : c+K+1) occurs"; the reference can also ask it for non-adjacent frames
-// (stale prev_frame after the `continue` at SMEM.py:94-95) -- then it is a positional test.
-__device__ __forceinline__ bool seq_check(const DevIndex &ix, const uint32_t *dir, const WaveScratch &ws, int c, int pc,
-                                          int lane)
-{
-    const int K = ix.K;
-    if (pc == c + 1) return rfl((int)ws.fwd[c]) >= c + K + 1;
-    const int2 iv = sa_interval(ix, dir, QWords{ws.qp}, c, K);     // wave-uniform inputs
-    if (iv.x < 0) return false;
-    const uint32_t want = (uint32_t)(qwin(ws.qp, pc) >> (64 - 2 * K));
-    bool found = false;
-    for (int r0 = iv.x; r0 <= iv.y; r0 += kWave) {
-        const int r = r0 + lane;
-        bool ok = false;
-        if (r <= iv.y) {
-            const int s1 = ix.sa[r].s + 1;
-            if (s1 + K <= ix.n) ok = (uint32_t)(rwin(ix.ref, s1) >> (64 - 2 * K)) == want;
-        }
-        found |= __any(ok) != 0;
-    }
-    return found;
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(1024) find_smems_kernel(DevIndex ix, const uint8_t *__restrict__ reads,
-                                                           const int32_t *__restrict__ lens, long long N, int stride,
-                                                           int fixed_len, int Lmax, int min_len,
-                                                           int32_t *__restrict__ counts, int4 *__restrict__ slots,
-                                                           int cap, int32_t *__restrict__ status, int leaf_in_lds)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = rfl((int)(threadIdx.x >> 6));       // wave-uniform by construction
-    const int waves_per_block = blockDim.x >> 6;
-
-    // ---- stage the read-only seed tables in LDS (once per persistent block)
-    uint32_t *dir = reinterpret_cast<uint32_t *>(smem);
-    const int dir_bytes = (ix.dir_entries * 4 + 15) & ~15;
-    for (int i = threadIdx.x; i < ix.dir_entries; i += blockDim.x) dir[i] = ix.dir[i];
-    const RmiModel *leaf = nullptr;
-    int leaf_bytes = 0;
-    if (MODE == GENIE_MODE_RMI && leaf_in_lds) {
-        const int l0 = ix.rmi_off[ix.nlev - 1], cnt = ix.rmi_off[ix.nlev] - l0;
-        double2 *dst = reinterpret_cast<double2 *>(smem + dir_bytes);
-        const double2 *src = reinterpret_cast<const double2 *>(ix.rmi + l0);
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
-        leaf = reinterpret_cast<const RmiModel *>(dst);
-        leaf_bytes = cnt * 16;
-    }
-    __syncthreads();
-
-    const WaveScratch ws = carve(smem + dir_bytes + leaf_bytes + wave * scratch_bytes(Lmax), Lmax);
-    const int K = ix.K;
-
-    for (long long r = (long long)blockIdx.x * waves_per_block + wave; r < N;
-         r += (long long)gridDim.x * waves_per_block) {
-        const int L = lens ? lens[r] : fixed_len;
-        int st = GENIE_READ_OK;
-        int cnt = 0;
-        if (L > Lmax || L < 0) {
-            st = GENIE_READ_BAD_BASE;                  // host validates lengths; defensive only
-        } else if (!load_and_pack(reads + r * (long long)stride, L, Lmax, ws, lane)) {
-            st = GENIE_READ_BAD_BASE;
-        } else if (MODE != GENIE_MODE_BWA && L < K) {
-            st = GENIE_READ_TOO_SHORT;
-        }
-
-        if (st == GENIE_READ_OK && L > 0) {
-            // ---------------- phase 1: fwd[a] for every a, one lane per position
-            int mymax = 0;
-            for (int a = lane; a < L; a += kWave) {
-                int len = 0;
-                bool seeded = false;
-                if (MODE != GENIE_MODE_BWA && a + K <= L) {
-                    const uint32_t code = (uint32_t)(qwin(ws.qp, a) >> (64 - 2 * K));
-                    int lo, hi;
-                    const bool hit = MODE == GENIE_MODE_LUT ? lut_probe(ix, code, lo, hi)
-                                                            : rmi_lookup(ix, leaf, code, lo, hi, nullptr);
-                    if (hit) {                         // forward extension from the seed interval
-                        len = ms_search(ix, QWords{ws.qp}, a, L - a, lo, hi + 1, K);
-                        seeded = true;
-                    }
-                }
-                if (!seeded) len = ms_generic(ix, dir, QWords{ws.qp}, a, L);
-                ws.fwd[a] = (uint16_t)(a + len);
-                mymax = len > mymax ? len : mymax;
-            }
-            if (lane == 0) ws.fwd[L] = (uint16_t)L;
-            const int M = (int)rflu(wave_max_u32((uint32_t)mymax));
-            wave_lds_fence();
-
-            // ---------------- phase 2: the reference's traversal, wave-uniform
-            const uint16_t *fwd = ws.fwd;
-#define FWD(i) rfl((int)fwd[(i)])
-#define EMIT(kk, jj)                                                          \
-    do {                                                                      \
-        if (lane == 0 && cnt < Lmax) ws.emit[cnt] = (uint32_t)(kk) | ((uint32_t)(jj) << 16); \
-        cnt++;                                                                \
-    } while (0)
-
-            if (MODE == GENIE_MODE_BWA) {
-                // SMEM.get_SMEMS (SMEM.py:456-467): i = 0; smem at i; i = its end
-                int i = 0;
-                while (i < L) {
-                    const int f = FWD(i);
-                    if (f == i) { st = GENIE_READ_ABSENT_BASE; break; }
-                    const Cand c = back_ext(fwd, i, i + 1, f, M, lane);      // get_SMEM_at_index :469-484
-                    if (c.len >= min_len) EMIT(c.k, c.j);
-                    i = c.j;
-                }
-            } else {
-                // SMEM.get_smems_lut / get_smems_rmi (SMEM.py:20-192 / 206-384)
-                const int f0 = FWD(0);
-                if (f0 == 0) {
-                    st = GENIE_READ_ABSENT_BASE;
-                } else {
-                    EMIT(0, f0);                                             // first SMEM (:26-39)
-                    int end = f0, prev_len = f0;
-                    while (end < L && st == GENIE_READ_OK) {                 // :49
-                        int pstate = 0, pc = 0;                              // 0 None, 1 (), 2 frame
-                        bool pfwd = false, have = false;
-                        Cand cur = {0, 0, 0};
-                        const int prev_start = end - prev_len;
-#define OFFER(LEN, KK, JJ)                                                    \
-    do {                                                                      \
-        if (!have || (LEN) >= cur.len) { cur.len = (LEN); cur.k = (KK); cur.j = (JJ); have = true; } \
-    } while (0)
-                        for (int i = 0; i < K; i++) {                        // :56
-                            if (i >= prev_len) break;                        // :57 (monotone in i)
-                            const int c = end - i;
-                            if (c + K > L) continue;                         // :62
-                            const int fc = FWD(c);
-                            if (fc >= c + K) {                               // seed hit (:67 / :253)
-                                if (pstate == 0) { pstate = 2; pc = c; pfwd = true; }
-                                else if (pstate == 1) { pstate = 2; pc = c; pfwd = false; }
-                                else {
-                                    const int fp = FWD(pc);
-                                    if (seq_check(ix, dir, ws, c, pc, lane)) {               // Case 1 (:75)
-                                        if (pfwd) {
-                                            const Cand b = back_ext(fwd, pc, pc + K, fp, M, lane);
-                                            OFFER(b.len, b.k, b.j);
-                                        } else {
-                                            if (have && (pc - prev_start) + K < cur.len) continue;   // :94-95
-                                            const Cand b = back_ext(fwd, pc, pc + K, pc + K, M, lane);
-                                            OFFER(b.len, b.k, b.j);
-                                        }
-                                    } else {                                                  // Case 2 (:108)
-                                        if (pfwd) OFFER(fp - pc, pc, fp);
-                                        else OFFER(K, c, c + K);                              // current K-mer (:119-122)
-                                    }
-                                    pc = c;
-                                    pfwd = false;
-                                }
-                            } else {                                                          // seed miss
-                                if (pstate == 2) {                                            // Case 3 (:129)
-                                    if (pfwd) { const int fp = FWD(pc); OFFER(fp - pc, pc, fp); }
-                                    else OFFER(K, pc, pc + K);
-                                }
-                                pstate = 1;
-                            }
-                        }
-                        if (pstate == 2) {                                                    // last frame (:149)
-                            const int fp = FWD(pc);
-                            const Cand b = pfwd ? back_ext(fwd, pc, pc + K, fp, M, lane)
-                                                : back_ext(fwd, pc, pc + K, pc + K, M, lane);
-                            OFFER(b.len, b.k, b.j);
-                        }
-                        if (!have) {                                                          // :175 BWA step
-                            const int f = FWD(end);
-                            if (f == end) { st = GENIE_READ_ABSENT_BASE; break; }
-                            cur = back_ext(fwd, end, end + 1, f, M, lane);
-                        }
-                        EMIT(cur.k, cur.j);
-                        end = cur.j;
-                        prev_len = cur.len;
-#undef OFFER
-                    }
-                }
-            }
-#undef EMIT
-#undef FWD
-            if (st != GENIE_READ_OK) cnt = 0;
-            wave_lds_fence();
-
-            // ---------------- phase 3: SA interval of every emitted SMEM, one lane each
-            const int nout = cnt < cap ? cnt : cap;
-            for (int t = lane; t < nout; t += kWave) {
-                const uint32_t e = ws.emit[t];
-                const int k = (int)(e & 0xFFFF), j = (int)(e >> 16);
-                const int2 iv = sa_interval(ix, dir, QWords{ws.qp}, k, j - k);
-                slots[r * (long long)cap + t] = make_int4(k, j, iv.x, iv.y);
-            }
-            if (cnt > cap) st = GENIE_READ_OVERFLOW;
-            wave_lds_fence();
-        }
-        if (lane == 0) {
-            counts[r] = cnt;
-            if (status) status[r] = st;
-        }
-    }
 }
 
 #include "short_read_kernel.inc"
@@ -852,17 +538,36 @@ std::string g_err;
     } while (0)
 
 struct Geometry {
-    int grid, block, lds, leaf_in_lds, Lmax;
-    int ns;          // > 0: short-read pipeline (K_A + K_B) for reads of at most 255 bases
-    int fwd_stride;  // bytes per fwd[] row in the workspace (multiple of 4, odd number of dwords)
+    int grid, block, lds, leaf_in_lds;
+    int ns;          // position slots per chunk in K_A (1..4)
+    int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
+    int max_len;
+    int fwd_stride;  // bytes per fwd[] row in the workspace
+    int qp_words;    // packed-read words per wave in LDS (incl. 2 zero words)
+    int qp_recs;     // 16-byte packed-read records per read in the workspace
+    int hm_words;    // hit-mask words per read + 1 (longest match)
+    int kj_row;      // emitted-pair entries per read
 };
 
-inline int fwd_row_bytes(int max_len)
+inline int fwd_row_bytes(int max_len, bool wide)
 {
+    if (wide) return ((max_len * 2) + 15) & ~15;
     int dw = (max_len + 3) / 4;
     if (dw < 1) dw = 1;
-    if ((dw & 1) == 0) dw++;
+    if ((dw & 1) == 0) dw++;              // odd dword stride: conflict-free LDS rows in K_B
     return dw * 4;
+}
+
+inline void shape_for(int max_len, Geometry *g)
+{
+    g->max_len = max_len;
+    g->wide = max_len > 255;
+    g->ns = g->wide ? 4 : std::max(1, (max_len + 63) / 64);
+    g->qp_words = g->wide ? (max_len + 31) / 32 + 2 : 2 * g->ns + 2;
+    g->qp_recs = g->qp_words - 2;
+    g->hm_words = (g->wide ? (max_len + 63) / 64 : g->ns) + 1;
+    g->fwd_stride = fwd_row_bytes(max_len, g->wide);
+    g->kj_row = (std::max(max_len, 1) + 7) & ~7;
 }
 
 int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
@@ -875,9 +580,8 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
         const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
         if (cnt * 16 <= 48 * 1024) leaf_bytes = cnt * 16;
     }
-    const int Lmax = std::max(32, (max_len + 31) / 32 * 32);
-    const int ns = max_len <= 255 ? std::max(1, (max_len + 63) / 64) : 0;
-    const int per_wave = ns ? (2 * ns + 2) * 8 : scratch_bytes(Lmax);
+    shape_for(max_len, g);
+    const int per_wave = g->qp_words * 8;
     int waves = (lds_cap - dir_bytes - leaf_bytes) / per_wave;
     if (waves < 1) return GENIE_E_TOO_LONG;
     if (waves > 16) waves = 16;
@@ -897,50 +601,45 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     g->block = waves * kWave;
     g->lds = lds;
     g->leaf_in_lds = leaf_bytes > 0;
-    g->Lmax = Lmax;
-    g->ns = ns;
-    g->fwd_stride = fwd_row_bytes(max_len);
     return GENIE_OK;
 }
 
 struct Workspace {
     uint8_t *fwd;        // N x fwd_stride bytes
-    RefRec *qp;          // 2*ns records of 16 bytes per read
+    RefRec *qp;          // qp_recs records of 16 bytes per read
     int32_t *status;     // used when the caller passes no status array
-    uint16_t *kj;        // N x kj_stride emitted (start | end << 8) pairs
-    unsigned long long *hm;  // N x (ns+1): K-mer hit mask per 64 positions + longest match
+    uint8_t *kj;         // N x kj_row emitted (start | end << shift) entries of 2 or 4 bytes
+    unsigned long long *hm;  // N x hm_words: K-mer hit mask per 64 positions + longest match
     int32_t *counts;     // used by the CSR entry point
     uint8_t *scan_tmp;   // scratch of the offsets scan (CSR entry point)
 };
 
 inline int64_t ws_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
-inline int kj_row(int max_len) { return (std::max(max_len, 1) + 7) & ~7; }       // entries per read (>= max SMEMs)
 
 inline int64_t workspace_bytes_for(int64_t N, int max_len)
 {
-    if (max_len > 255) return 0;
-    const int ns = std::max(1, (max_len + 63) / 64);
-    return ws_align(N * (int64_t)fwd_row_bytes(max_len)) + ws_align(N * (int64_t)(2 * ns) * 16) + ws_align(N * 4) +
-           ws_align(N * (int64_t)kj_row(max_len) * 2) + ws_align(N * (int64_t)(ns + 1) * 8) + ws_align(N * 4) +
+    Geometry g;
+    shape_for(max_len, &g);
+    return ws_align(N * (int64_t)g.fwd_stride) + ws_align(N * (int64_t)g.qp_recs * 16) + ws_align(N * 4) +
+           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * (int64_t)g.hm_words * 8) + ws_align(N * 4) +
            ws_align(compact_tmp_bytes(N)) + 256;
 }
 
-inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, int max_len, Workspace *ws)
+inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geometry &g, Workspace *ws)
 {
-    if (!d_ws || ws_bytes < workspace_bytes_for(N, max_len) || (reinterpret_cast<uintptr_t>(d_ws) & 255) != 0)
+    if (!d_ws || ws_bytes < workspace_bytes_for(N, g.max_len) || (reinterpret_cast<uintptr_t>(d_ws) & 255) != 0)
         return GENIE_E_CAPACITY;
-    const int ns = std::max(1, (max_len + 63) / 64);
     uint8_t *p = reinterpret_cast<uint8_t *>(d_ws);
     ws->fwd = p;
-    p += ws_align(N * (int64_t)fwd_row_bytes(max_len));
+    p += ws_align(N * (int64_t)g.fwd_stride);
     ws->qp = reinterpret_cast<RefRec *>(p);
-    p += ws_align(N * (int64_t)(2 * ns) * 16);
+    p += ws_align(N * (int64_t)g.qp_recs * 16);
     ws->status = reinterpret_cast<int32_t *>(p);
     p += ws_align(N * 4);
-    ws->kj = reinterpret_cast<uint16_t *>(p);
-    p += ws_align(N * (int64_t)kj_row(max_len) * 2);
+    ws->kj = p;
+    p += ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2));
     ws->hm = reinterpret_cast<unsigned long long *>(p);
-    p += ws_align(N * (int64_t)(ns + 1) * 8);
+    p += ws_align(N * (int64_t)g.hm_words * 8);
     ws->counts = reinterpret_cast<int32_t *>(p);
     p += ws_align(N * 4);
     ws->scan_tmp = p;
@@ -953,31 +652,31 @@ struct CsrOut {
     int64_t cap_rows = 0;
 };
 
-template <int MODE, int NS>
-int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
-                 int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots, int32_t cap,
-                 int32_t *d_status, const Workspace &ws, const CsrOut &csr, hipStream_t s)
+template <int MODE, int NS, bool WIDE>
+int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
+                    int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots, int32_t cap,
+                    int32_t *d_status, const Workspace &ws, const CsrOut &csr, hipStream_t s)
 {
     int32_t *st = d_status ? d_status : ws.status;
     int32_t *cnt = d_counts ? d_counts : ws.counts;
-    const int kjs = kj_row(fixed_len);
-    auto ka = match_stats_kernel<MODE, NS>;
+    auto ka = match_stats_kernel<MODE, NS, WIDE>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
-                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, ws.hm, st, g.leaf_in_lds, ix->opt_lut_probe);
+                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st, g.leaf_in_lds,
+                       ix->opt_lut_probe);
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
-    auto kb = traverse_kernel<MODE>;
+    auto kb = traverse_kernel<MODE, WIDE>;
     const int tb = 256;
-    const int lds_b = tb * g.fwd_stride;
+    const int lds_b = WIDE ? 0 : tb * g.fwd_stride;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, 2 * NS, ws.hm, NS + 1, cnt, ws.kj, kjs,
-                       csr.offsets ? kjs : cap, st);
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, cnt, ws.kj, g.kj_row,
+                       csr.offsets ? g.kj_row : cap, st);
     HIP_TRY(hipGetLastError());
     if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
-        int rc = launch_compact(cnt, nullptr, N, kjs, csr.offsets, nullptr, 0, ws.scan_tmp, s);
+        int rc = launch_compact(cnt, nullptr, N, g.kj_row, csr.offsets, nullptr, 0, ws.scan_tmp, s);
         if (rc) return rc;
     }
     // K_C: intervals + final rows, 16 lanes per read, persistent blocks with the directory in LDS
@@ -989,16 +688,16 @@ int launch_short(const genie_index *ix, const Geometry &g, const uint8_t *d_read
     const long long need_c = (N + 63) / 64;
     if (grid_c > need_c) grid_c = need_c;
     if (csr.offsets) {
-        auto kc = interval_kernel<true>;
+        auto kc = interval_kernel<true, WIDE>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
-        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, kjs, ws.qp,
-                           2 * NS, reinterpret_cast<int4 *>(csr.rows), 0, reinterpret_cast<const long long *>(csr.offsets),
-                           (long long)csr.cap_rows);
+        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, g.kj_row,
+                           ws.qp, g.qp_recs, reinterpret_cast<int4 *>(csr.rows), 0,
+                           reinterpret_cast<const long long *>(csr.offsets), (long long)csr.cap_rows);
     } else {
-        auto kc = interval_kernel<false>;
+        auto kc = interval_kernel<false, WIDE>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
-        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, kjs, ws.qp,
-                           2 * NS, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
+        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, g.kj_row,
+                           ws.qp, g.qp_recs, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
     }
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -1009,34 +708,21 @@ int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_
                      int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,
                      int32_t cap, int32_t *d_status, void *d_ws, int64_t ws_bytes, const CsrOut &csr, hipStream_t s)
 {
-    if (g.ns > 0) {
-        Workspace ws;
-        int rc = carve_workspace(d_ws, ws_bytes, N, fixed_len, &ws);
-        if (rc) return rc;
-#define GENIE_SHORT(NS_)                                                                                        \
-    case NS_:                                                                                                   \
-        return launch_short<MODE, NS_>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, \
-                                       cap, d_status, ws, csr, s)
-        switch (g.ns) {
-            GENIE_SHORT(1);
-            GENIE_SHORT(2);
-            GENIE_SHORT(3);
-            GENIE_SHORT(4);
-        default:
-            return GENIE_E_INVALID;
-        }
-#undef GENIE_SHORT
+    Workspace ws;
+    int rc = carve_workspace(d_ws, ws_bytes, N, g, &ws);
+    if (rc) return rc;
+#define GENIE_PIPE(NS_, WIDE_)                                                                                        \
+    return launch_pipeline<MODE, NS_, WIDE_>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, \
+                                             cap, d_status, ws, csr, s)
+    if (g.wide) GENIE_PIPE(4, true);
+    switch (g.ns) {
+    case 1: GENIE_PIPE(1, false);
+    case 2: GENIE_PIPE(2, false);
+    case 3: GENIE_PIPE(3, false);
+    case 4: GENIE_PIPE(4, false);
     }
-    if (csr.offsets) return GENIE_E_TOO_LONG;        // the fused CSR entry point covers the short-read pipeline
-    auto kern = find_smems_kernel<MODE>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-    if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
-    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
-                       fixed_len, g.Lmax, min_len, d_counts, reinterpret_cast<int4 *>(d_slots), cap, d_status,
-                       g.leaf_in_lds);
-    HIP_TRY(hipGetLastError());
-    if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
-    return GENIE_OK;
+#undef GENIE_PIPE
+    return GENIE_E_INVALID;
 }
 
 }  // namespace

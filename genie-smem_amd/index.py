@@ -236,8 +236,7 @@ class GenieIndex:
 
     def find_smems(self, mode, reads, lens=None, min_len=1, cap=None, rows_hint=None):
         """Batched SMEM discovery -> (offsets int64[N+1], smems int32[S,4] = (start,end,lo,hi), status).
-        Reads of at most 255 bases go through the fused CSR entry point (genie_find_smems_csr);
-        longer ones through the slotted kernel + compaction."""
+        Uses the fused CSR entry point (genie_find_smems_csr) unless an explicit slot capacity is asked for."""
         self._need_device()
         reads = self._as_dev(reads, torch.uint8)
         if reads.dim() != 2:
@@ -249,7 +248,7 @@ class GenieIndex:
             fixed = int(lens.max().item()) if n_reads else 0
             if fixed > stride or (n_reads and int(lens.min().item()) < 0):
                 raise ValueError("read length outside [0, stride]")
-        if fixed > 255 or cap is not None or n_reads == 0 or stride == 0:
+        if cap is not None or n_reads == 0 or stride == 0:
             counts, slots, status = self.find_smems_slots(mode, reads, lens, min_len, cap)
             offsets, out = self.compact(counts, slots)
             total = int(offsets[-1].item())

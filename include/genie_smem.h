@@ -161,16 +161,15 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
  * d_status[r] (may be NULL) = GENIE_READ_* code.  `cap` slots per read (cap >= max read
  * length never overflows).
  * d_workspace: 256-byte aligned device scratch of genie_find_smems_workspace_bytes(N, max_len)
- * bytes (matching statistics handed from the search kernel to the traversal kernel; 0 bytes --
- * pointer may be NULL -- for reads longer than 255 bases, which take the single-kernel path). */
+ * bytes (matching statistics, packed reads, hit masks and emitted (start, end) pairs handed between
+ * the kernels of the pipeline). */
 int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len);
 int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
                      int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
                      int32_t *d_slots, int32_t cap, int32_t *d_status, void *d_workspace, int64_t workspace_bytes,
                      void *stream);
 
-/* Same discovery, CSR output in one call (reads of at most 255 bases; longer: GENIE_E_TOO_LONG, use
- * genie_find_smems + genie_compact_smems): d_offsets[N+1] = exclusive prefix sum of the per-read SMEM
+/* Same discovery, CSR output in one call: d_offsets[N+1] = exclusive prefix sum of the per-read SMEM
  * counts, d_rows[4*t .. 4*t+3] = (start, end, lo, hi) of SMEM t, reads in input order, SMEMs in the
  * reference's emission order.  Every row is written exactly once; rows beyond out_cap_rows are
  * dropped (the caller compares d_offsets[N] with its capacity).  Flagged reads contribute no rows. */
