@@ -14,9 +14,21 @@ struct uint2 { unsigned int x, y; };
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 3;
+constexpr uint32_t kBlobVersion = 4;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
+
+// Second-level range table entry: the rows [lb, lb + cnt) whose suffix starts with this P2-mer
+// (cnt == 0: absent) and a copy of the FIRST row's inline key, so that one 16-byte load both
+// bounds the search and serves as its first probe.  kHeadShort marks a first row whose suffix has
+// fewer than P + 32 bases (its key is zero padded): such an entry is used as a range only.
+struct HeadRec {
+    uint32_t lb;
+    uint32_t meta;        // cnt | kHeadShort
+    uint64_t key;
+};
+static_assert(sizeof(HeadRec) == 16, "HeadRec layout");
+constexpr uint32_t kHeadShort = 0x80000000u;
 
 // One slot of the device K-mer hash table (the GPU form of the reference's `lut` dict,
 // SMEM/LUT.py:33-35): key -> inclusive SA interval.  Empty slot: lo < 0.
@@ -77,7 +89,7 @@ struct BlobHeader {
     int32_t rmi_scale[GENIE_MAX_RMI_LEVELS];
     int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1];
     uint32_t padtail[8];  // padtail[l] = code(last l bases) << 2(P-l) for l < P, kNoTail if l > n
-    int64_t off_dir2;     // uint32 pairs [4^P2]: exact row range [lb, ub) of every P2-mer (lb == ub: absent)
+    int64_t off_dir2;     // HeadRec [4^P2]: rows of every P2-mer + the inline key of the first of them
     int64_t dir2_entries;
     int32_t P2;           // 0 = no second-level table
     int32_t pad2;
@@ -92,7 +104,7 @@ struct DevIndex {
     const uint32_t *dir;
     const LutSlot *lut;
     const RmiModel *rmi;
-    const uint2 *dir2;     // second-level range table (global, L2-resident), or null
+    const HeadRec *dir2;   // second-level range table (global, L2-resident), or null
     int32_t n;
     int32_t K;
     int32_t P;
@@ -120,7 +132,7 @@ struct HostIndex {
     std::vector<RefRec> ref;
     std::vector<uint32_t> dir;
     int32_t P2 = 0;
-    std::vector<uint32_t> dir2;          // 2 x 4^P2: lb, ub interleaved
+    std::vector<HeadRec> dir2;           // 4^P2 entries
     std::vector<uint32_t> lut_code;      // sorted distinct K-mers
     std::vector<int32_t> lut_lo, lut_hi;
     std::vector<LutSlot> lut_slots;

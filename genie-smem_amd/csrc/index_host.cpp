@@ -171,15 +171,23 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
         if (n >= 65536) {
             int P2 = P + 1;
             while (P2 < 12 && ((int64_t)1 << (2 * P2)) < n / 2) P2++;
+            if (const char *e = std::getenv("GENIE_DIR2_BITS")) {       // build-time tuning knob
+                const int v = std::atoi(e);
+                if (v > P && v <= 12) P2 = v;
+            }
             h->P2 = P2;
             const int64_t nb2 = (int64_t)1 << (2 * P2);
-            h->dir2.assign((size_t)(2 * nb2), 0);
+            h->dir2.assign((size_t)nb2, HeadRec{0, 0, 0});
             for (int64_t r = 0; r < rows; r++) {
                 const int64_t s = h->sa0[(size_t)r];
                 if (n - s < P2) continue;
-                const uint64_t c = code_at64(codes, s, P2);
-                if (h->dir2[(size_t)(2 * c)] == h->dir2[(size_t)(2 * c + 1)]) h->dir2[(size_t)(2 * c)] = (uint32_t)r;
-                h->dir2[(size_t)(2 * c + 1)] = (uint32_t)(r + 1);
+                HeadRec &e = h->dir2[(size_t)code_at64(codes, s, P2)];
+                if ((e.meta & ~kHeadShort) == 0) {
+                    e.lb = (uint32_t)r;
+                    e.key = h->sarec[(size_t)r].key;
+                    e.meta = (n - s < P + 32) ? kHeadShort : 0;
+                }
+                e.meta++;
             }
         }
 
@@ -237,7 +245,7 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->lut_keys = (int64_t)h.lut_code.size();
     hdr->rmi_models = (int64_t)h.rmi.size();
     hdr->P2 = h.P2;
-    hdr->dir2_entries = (int64_t)h.dir2.size() / 2;
+    hdr->dir2_entries = (int64_t)h.dir2.size();
     hdr->nlev = h.nlev;
     for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
         hdr->rmi_size[l] = h.rmi_size[l];
@@ -257,7 +265,7 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->off_rmi = off;
     off = align_up(off + (int64_t)std::max<size_t>(h.rmi.size(), 1) * (int64_t)sizeof(RmiModel));
     hdr->off_dir2 = off;
-    off = align_up(off + (int64_t)std::max<size_t>(h.dir2.size(), 2) * 4);
+    off = align_up(off + (int64_t)std::max<size_t>(h.dir2.size(), 1) * (int64_t)sizeof(HeadRec));
     hdr->total_bytes = off;
 }
 
@@ -274,7 +282,7 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     memcpy(p + hdr.off_dir, h.dir.data(), h.dir.size() * 4);
     memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
     if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
-    if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * 4);
+    if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * sizeof(HeadRec));
     return GENIE_OK;
 }
 
@@ -293,7 +301,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->dir = (const uint32_t *)(p + hdr.off_dir);
     out->lut = (const LutSlot *)(p + hdr.off_lut);
     out->rmi = (const RmiModel *)(p + hdr.off_rmi);
-    out->dir2 = hdr.P2 > 0 ? (const uint2 *)(p + hdr.off_dir2) : nullptr;
+    out->dir2 = hdr.P2 > 0 ? (const HeadRec *)(p + hdr.off_dir2) : nullptr;
     out->P2 = hdr.P2;
     out->n = (int32_t)hdr.n;
     out->K = hdr.K;

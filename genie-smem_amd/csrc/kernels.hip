@@ -319,26 +319,41 @@ __device__ __forceinline__ int2 sa_interval(const DevIndex &ix, const uint32_t *
         const int lb = (int)dir_lb(ix, dir, code, m), ub = (int)dir_ub(ix, dir, code, m);
         return lb < ub ? make_int2(lb, ub - 1) : make_int2(-1, -1);
     }
-    const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
-    int lo = (int)dir[b];
-    int hi = (int)dir_ub(ix, dir, b, P);
-    if (ix.P2 && m >= ix.P2) {                         // second-level table: exact rows of the first P2 bases
-        const uint2 pr = ix.dir2[(uint32_t)(w >> (64 - 2 * ix.P2))];
-        if (pr.x >= pr.y) return make_int2(-1, -1);
-        lo = (int)pr.x;
-        hi = (int)pr.y;
-    }
     const uint64_t xq = qp.win(a + P);
-    int h = hi;
+    int lo, hi, h;
+    int known = -1;                                     // a row known to carry the pattern as prefix
+    if (ix.P2 && m >= ix.P2) {
+        // second-level table: exact rows of the first P2 bases + the first row's inline key (first probe)
+        int4 hd = *reinterpret_cast<const int4 *>(ix.dir2 + (uint32_t)(w >> (64 - 2 * ix.P2)));
+        asm volatile("" : "+v"(hd.x), "+v"(hd.y), "+v"(hd.z), "+v"(hd.w));
+        const uint32_t cnt = (uint32_t)hd.y & ~kHeadShort;
+        if (cnt == 0) return make_int2(-1, -1);
+        lo = hd.x;
+        hi = h = hd.x + (int)cnt;
+        const uint64_t key = ((uint64_t)(uint32_t)hd.w << 32) | (uint32_t)hd.z;
+        const uint64_t x = xq ^ key;
+        if (!((uint32_t)hd.y & kHeadShort) && (x != 0 || m <= P + 32)) {      // decided inside the key
+            const int l = x ? P + (__clzll((long long)x) >> 1) : m;
+            if (l >= m) { h = lo; known = lo; }                              // row lb matches: it is the lower bound
+            else if (key < xq) lo = lo + 1;
+            else h = lo;                                                      // row lb > pattern, no match: absent
+        }
+    } else {
+        const uint32_t b = (uint32_t)(w >> (64 - 2 * P));
+        lo = (int)dir[b];
+        hi = h = (int)dir_ub(ix, dir, b, P);
+    }
     uint32_t vlo = 0, vhi = 0xFFFFFFFFu;
     int step = 0;
     while (lo < h) {                                    // first row whose suffix is not < pattern
         const int mid = pick_probe(lo, h, (uint32_t)(xq >> 32), vlo, vhi, step++);
         const SaRec rec = load_rec(ix.sa, mid);
-        if (cmp_rec(ix, qp, a, m, rec, xq).less) { lo = mid + 1; vlo = (uint32_t)(rec.key >> 32); }
-        else { h = mid; vhi = (uint32_t)(rec.key >> 32); }
+        const Cmp c = cmp_rec(ix, qp, a, m, rec, xq);
+        if (c.less) { lo = mid + 1; vlo = (uint32_t)(rec.key >> 32); }
+        else { h = mid; vhi = (uint32_t)(rec.key >> 32); known = c.l >= m ? mid : -1; }
     }
     const int first = lo;
+    if (known == first) lo = first + 1;                 // already seen to match: start above it
     h = hi;
     // first row that no longer has the pattern as prefix: matching rows are adjacent to `first`
     // (usually one or two), so gallop up from it and bisect the last gap

@@ -231,7 +231,8 @@ def test_rmi_fit_is_a_usable_model(pkg):
 
 
 def test_second_level_range_table(pkg):
-    """dir2[b] = exact [lb, ub) rows of every P2-mer b (lb == ub: absent), checked against the suffix array."""
+    """dir2[b] = {lb, cnt | short flag, key of row lb} for every P2-mer b (cnt == 0: absent), checked
+    against the suffix array and the suffix-array records."""
     d, _ = G.load("syn100k_K15")
     ref = d["ref_codes"]
     ix = pkg.GenieIndex.build(ref, 15)
@@ -239,7 +240,16 @@ def test_second_level_range_table(pkg):
     h = _parse(img)
     P2 = h["P2"]
     assert P2 == 8 and h["dir2_entries"] == 4 ** P2
-    pairs = np.frombuffer(bytes(img[h["off_dir2"]:h["off_dir2"] + 8 * h["dir2_entries"]]), np.uint32).reshape(-1, 2)
+    head = np.frombuffer(bytes(img[h["off_dir2"]:h["off_dir2"] + 16 * h["dir2_entries"]]),
+                         np.dtype([("lb", "<u4"), ("meta", "<u4"), ("key", "<u8")]))
+    cnt = (head["meta"] & 0x7FFFFFFF).astype(np.int64)
+    pairs = np.stack([head["lb"].astype(np.int64), head["lb"].astype(np.int64) + cnt], axis=1)
+    sarec = np.frombuffer(bytes(img[h["off_sa"]:h["off_sa"] + 16 * (len(ref) + 1)]),
+                          np.dtype([("s", "<i4"), ("pad", "<i4"), ("key", "<u8")]))
+    occ = cnt > 0
+    assert (head["key"][occ] == sarec["key"][head["lb"][occ]]).all()                  # copy of the first row's key
+    short = (head["meta"][occ] >> 31).astype(bool)
+    assert (short == (len(ref) - sarec["s"][head["lb"][occ]] < h["P"] + 32)).all()
     sa0 = ix.suffix_array().astype(np.int64) - 1
     n = len(ref)
     full = sa0 + P2 <= n
