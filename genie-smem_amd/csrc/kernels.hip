@@ -217,15 +217,15 @@ __device__ __forceinline__ bool lut_probe(const DevIndex &ix, uint32_t code, int
 
 // RMI.predict for one key (SMEM/RMI.py:52-69): per level p = coef*x + intercept, rounded after
 // the multiply and after the add (sklearn computes X @ coef_ + intercept_), next expert =
-// min(scale-1, max(0, int(p))).  `leaf` = last level's models staged in LDS (or nullptr).
-__device__ __forceinline__ double rmi_predict(const DevIndex &ix, const RmiModel *leaf, uint32_t code)
+// min(scale-1, max(0, int(p))).  `leaf` = the first `leaf_cnt` models of the last level staged in LDS (or nullptr).
+__device__ __forceinline__ double rmi_predict(const DevIndex &ix, const RmiModel *leaf, int leaf_cnt, uint32_t code)
 {
     const double x = (double)code;
     double p = 0.0;
     int idx = 0;
     for (int l = 0; l < ix.nlev; l++) {
         double2 m;
-        if (leaf && l == ix.nlev - 1) m = *reinterpret_cast<const double2 *>(leaf + idx);        // LDS
+        if (leaf && l == ix.nlev - 1 && idx < leaf_cnt) m = *reinterpret_cast<const double2 *>(leaf + idx);   // LDS
         else m = *reinterpret_cast<const double2 *>(ix.rmi + ix.rmi_off[l] + idx);               // global
         p = __dadd_rn(__dmul_rn(m.x, x), m.y);
         const int scale = ix.rmi_scale[l];
@@ -257,7 +257,7 @@ __device__ __forceinline__ int kmer_cmp_row(const DevIndex &ix, int r, uint32_t 
 __device__ __forceinline__ bool rmi_lookup(const DevIndex &ix, const RmiModel *leaf, uint32_t code, int &lo, int &hi,
                                            double *pred_out)
 {
-    const double p = rmi_predict(ix, leaf, code);
+    const double p = rmi_predict(ix, leaf, 0, code);
     if (pred_out) *pred_out = p;
     const int rows = ix.n + 1;
     const int r0 = !(p > 0.0) ? 0 : (p >= (double)rows ? rows - 1 : (int)p);     // int(start_sa), clamped
@@ -590,13 +590,17 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     const DevIndex &d = ix->dev;
     const int dir_bytes = (d.dir_entries * 4 + 15) & ~15;
     const int lds_cap = 160 * 1024;
+    shape_for(max_len, g);
+    const int per_wave = g->qp_words * 8;
+    // RMI leaf models: as many as fit beside the directory while TWO 16-wave blocks still share a CU's
+    // LDS (experts [1000] = 16 000 B fit but for ~30 models); the rest are read from global memory.
     int leaf_bytes = 0;
     if (mode == GENIE_MODE_RMI) {
         const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
-        if (cnt * 16 <= 48 * 1024) leaf_bytes = cnt * 16;
+        int room = lds_cap / 2 - dir_bytes - 16 * per_wave;
+        if (room < 0) room = 0;
+        leaf_bytes = std::min(cnt, room / 16) * 16;
     }
-    shape_for(max_len, g);
-    const int per_wave = g->qp_words * 8;
     int waves = (lds_cap - dir_bytes - leaf_bytes) / per_wave;
     if (waves < 1) return GENIE_E_TOO_LONG;
     if (waves > 16) waves = 16;
@@ -615,7 +619,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     g->grid = (int)grid;
     g->block = waves * kWave;
     g->lds = lds;
-    g->leaf_in_lds = leaf_bytes > 0;
+    g->leaf_in_lds = leaf_bytes / 16;     // number of leaf models staged
     return GENIE_OK;
 }
 
