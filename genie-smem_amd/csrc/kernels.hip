@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 
@@ -554,6 +555,8 @@ std::string g_err;
 
 struct Geometry {
     int grid, block, lds, leaf_in_lds;
+    int blocks_a;    // paired search: blocks [0, blocks_a) take role A, the rest role B
+    int pair;        // narrow fixed-length batch whose last slot holds <= 32 positions: two reads per wave iteration
     int ns;          // position slots per chunk in K_A (1..4)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
     int max_len;
@@ -585,13 +588,14 @@ inline void shape_for(int max_len, Geometry *g)
     g->kj_row = (std::max(max_len, 1) + 7) & ~7;
 }
 
-int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
+int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len, long long N, Geometry *g)
 {
     const DevIndex &d = ix->dev;
     const int dir_bytes = (d.dir_entries * 4 + 15) & ~15;
     const int lds_cap = 160 * 1024;
     shape_for(max_len, g);
-    const int per_wave = g->qp_words * 8;
+    g->pair = !g->wide && fixed_len && max_len > 0 && max_len - 64 * (g->ns - 1) <= 32;
+    const int per_wave = g->qp_words * 8 * (g->pair ? 2 : 1);     // a wave packs one or two reads per iteration
     // RMI leaf models: as many as fit beside the directory while TWO 16-wave blocks still share a CU's
     // LDS (experts [1000] = 16 000 B fit but for ~30 models); the rest are read from global memory.
     int leaf_bytes = 0;
@@ -613,9 +617,21 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
     long long grid = (long long)cus * blocks_per_cu;
-    const long long need = (N + waves - 1) / waves;
+    const long long per_block = (long long)waves * (g->pair ? 2 : 1);
+    const long long need = (N + per_block - 1) / per_block;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
+    g->blocks_a = (int)grid;
+    if (g->pair && g->ns > 1) {
+        // two block roles (see match_stats_kernel); 48 % of the blocks in role A balances the two
+        // loops for 150-base reads in all three modes (measured optimum 45..50 %)
+        if (grid < 2) grid = 2;
+        int pct = 48;
+        if (const char *e = std::getenv("GENIE_PAIR_SPLIT")) { const int v = std::atoi(e); if (v > 0 && v < 100) pct = v; }
+        long long a = (grid * pct + 50) / 100;
+        a = a < 1 ? 1 : (a > grid - 1 ? grid - 1 : a);
+        g->blocks_a = (int)a;
+    }
     g->grid = (int)grid;
     g->block = waves * kWave;
     g->lds = lds;
@@ -678,12 +694,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
 {
     int32_t *st = d_status ? d_status : ws.status;
     int32_t *cnt = d_counts ? d_counts : ws.counts;
-    auto ka = match_stats_kernel<MODE, NS, WIDE>;
+    constexpr bool CANPAIR = !WIDE;
+    auto ka = (CANPAIR && g.pair) ? match_stats_kernel<MODE, NS, WIDE, CANPAIR> : match_stats_kernel<MODE, NS, WIDE, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
                        fixed_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st, g.leaf_in_lds,
-                       ix->opt_lut_probe);
+                       ix->opt_lut_probe, g.blocks_a);
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     auto kb = traverse_kernel<MODE, WIDE>;
@@ -762,7 +779,7 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
                         int32_t *lds_bytes)
 {
     Geometry g;
-    int rc = plan_find_smems(ix, mode, max_len, 1ll << 40, &g);
+    int rc = plan_find_smems(ix, mode, max_len, true, 1ll << 40, &g);
     if (rc) return rc;
     if (grid) *grid = g.grid;
     if (block) *block = g.block;
@@ -778,7 +795,7 @@ static int launch_find_any(const genie_index *ix, int32_t mode, const uint8_t *d
 {
     Geometry g;
     // with ragged lengths `fixed_len` carries the maximum length (host contract)
-    int rc = plan_find_smems(ix, mode, fixed_len, N, &g);
+    int rc = plan_find_smems(ix, mode, fixed_len, d_lens == nullptr, N, &g);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (mode) {

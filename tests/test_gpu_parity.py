@@ -257,6 +257,35 @@ def test_vs_oracle_fresh_reads(pkg, oracle_mod, ds, L, kind, algo):
         assert rows[r].tolist() == out[r, :counts[r]].tolist(), r
 
 
+@pytest.mark.parametrize("algo", ["bwa", "lut", "rmi"])
+def test_fixed_length_slot_layouts(pkg, oracle_mod, algo):
+    """Fixed-length batches whose last 64-position slot holds at most 32 positions are searched two reads
+    per wave with a shared slot; lengths on both sides of every boundary, an odd batch (last read has
+    no partner), and flagged reads inside pairs."""
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ix = _index_for(pkg, "syn100k_K15", algo)
+    o = oracle_mod.Oracle(d["ref_codes"], 15)
+    if algo == "rmi":
+        o.set_rmi([], [np.asarray([o.n / 4.0 ** o.K])], [np.asarray([0.0])])
+    for L in (15, 20, 31, 32, 33, 64, 65, 70, 96, 97, 128, 129, 131, 134, 150, 160, 161, 192, 193, 200, 224, 225, 255):
+        n_reads = 301
+        rd = B.reads_from_ref(d["ref_codes"], n_reads, L, 1000 + L)
+        rd[7, L // 2] = 5                       # flagged read as the second of a pair
+        rd[10, 0] = 4                           # ... and as the first
+        rd[300, L - 1] = 7 if L % 2 else rd[300, L - 1]          # sometimes the partnerless last read too
+        offsets, smems, st = ix.find_smems(algo, rd)
+        st = st.cpu().numpy()
+        rows = _rows_per_read(offsets, smems)
+        bad = {7, 10} | ({300} if L % 2 else set())
+        good = np.asarray([r for r in range(n_reads) if r not in bad])
+        counts, out = o.find_smems_batch(algo, np.ascontiguousarray(rd[good]), nthreads=8)
+        for r in bad:
+            assert st[r] == pkg._native.READ_BAD_BASE and len(rows[r]) == 0, (L, r)
+        for i, r in enumerate(good):
+            assert st[r] == 0 and rows[r].tolist() == out[i, :counts[i]].tolist(), (L, int(r))
+
+
 def test_lut_probe_option_changes_nothing(pkg):
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
