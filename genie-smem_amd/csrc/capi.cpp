@@ -262,6 +262,19 @@ int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t
     return launch_compact(d_counts, d_slots, N, cap, d_offsets, d_out, out_cap_rows, d_tmp, stream);
 }
 
+int64_t genie_locate_tmp_bytes(int64_t S) { return S < 0 ? 0 : locate_tmp_bytes(S); }
+
+int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_pos_offsets,
+                 int32_t *d_positions, int64_t cap_positions, void *d_tmp, int64_t tmp_bytes, void *stream)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    if (S < 0 || stride < 2 || !d_pos_offsets || cap_positions < 0 || (S > 0 && !d_lohi) ||
+        (cap_positions > 0 && !d_positions))
+        return GENIE_E_INVALID;
+    return launch_locate(ix, d_lohi, stride, S, d_pos_offsets, d_positions, cap_positions, d_tmp, tmp_bytes, stream);
+}
+
 int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
                       int32_t *lds_bytes)
 {

@@ -184,6 +184,9 @@ int launch_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_
 int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap, int64_t *d_offsets,
                    int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
 int64_t compact_tmp_bytes(int64_t N);
+int64_t locate_tmp_bytes(int64_t S);
+int launch_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_offsets,
+                  int32_t *d_positions, int64_t cap, void *d_tmp, int64_t tmp_bytes, void *stream);
 int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
                         int32_t *lds_bytes);
 void set_hip_error(const char *what, int code);

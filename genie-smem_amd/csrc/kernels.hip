@@ -470,12 +470,16 @@ constexpr int kScanBlock = 1024;
 __global__ void __launch_bounds__(kScanBlock) compact_block_sums(const int32_t *__restrict__ counts, long long N, int cap,
                                                                  unsigned long long *__restrict__ block_sums)
 {
-    __shared__ unsigned int wsum[kScanBlock / kWave];
+    __shared__ unsigned long long wsum[kScanBlock / kWave];
     const long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
-    unsigned int v = 0;
-    if (i < N) { const int c = counts[i]; v = (unsigned)(c < 0 ? 0 : (c < cap ? c : cap)); }
+    unsigned long long v = 0;                                  // 64-bit sums: interval sizes (genie_locate) can be large
+    if (i < N) { const int c = counts[i]; v = (unsigned long long)(c < 0 ? 0 : (c < cap ? c : cap)); }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += (unsigned)__shfl_xor((int)v, off, kWave);
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int lo = (unsigned)__shfl_xor((int)(unsigned)v, off, kWave);
+        const unsigned int hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, kWave);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -517,14 +521,14 @@ __global__ void __launch_bounds__(kScanBlock) compact_scatter(const int32_t *__r
                                                               long long *__restrict__ offsets, int4 *__restrict__ out,
                                                               long long out_cap_rows, int *__restrict__ overflow)
 {
-    __shared__ unsigned int part[kScanBlock];
+    __shared__ unsigned long long part[kScanBlock];
     const long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
-    unsigned int v = 0;
-    if (i < N) { const int c = counts[i]; v = (unsigned)(c < 0 ? 0 : (c < cap ? c : cap)); }
+    unsigned long long v = 0;
+    if (i < N) { const int c = counts[i]; v = (unsigned long long)(c < 0 ? 0 : (c < cap ? c : cap)); }
     part[threadIdx.x] = v;
     __syncthreads();
     for (int off = 1; off < kScanBlock; off <<= 1) {
-        unsigned int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        unsigned long long add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
         __syncthreads();
         part[threadIdx.x] += add;
         __syncthreads();
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_scatter(const int32_t *__r
         } else if ((long long)(base + v) > out_cap_rows) {
             *overflow = 1;
         } else {
-            for (unsigned int t = 0; t < v; t++) out[base + t] = slots[i * (long long)cap + t];
+            for (unsigned int t = 0; t < (unsigned int)v; t++) out[base + t] = slots[i * (long long)cap + t];
         }
     }
 }
@@ -900,6 +904,75 @@ int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, i
                        reinterpret_cast<const int4 *>(d_slots), (long long)N, cap, sums,
                        reinterpret_cast<long long *>(d_offsets), reinterpret_cast<int4 *>(d_out), (long long)out_cap_rows,
                        overflow);
+    HIP_TRY(hipGetLastError());
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------ position resolution (rows -> coordinates)
+namespace {
+
+__global__ void __launch_bounds__(256) locate_count_kernel(const int32_t *__restrict__ lohi, int stride, long long S,
+                                                           int32_t *__restrict__ counts)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S) return;
+    const int lo = lohi[g * stride], hi = lohi[g * stride + 1];
+    counts[g] = (lo >= 0 && hi >= lo) ? hi - lo + 1 : 0;
+}
+
+// ExactMatch.get_positions (ExactMatch.py:195-199): the suffix-array entries of rows lo..hi, 1-based, in
+// row order.  One lane per interval (almost all hold one or two rows); an interval of more than 32 rows
+// is copied by the whole wave.
+__global__ void __launch_bounds__(256) locate_scatter_kernel(DevIndex ix, const int32_t *__restrict__ lohi, int stride,
+                                                             long long S, const long long *__restrict__ offsets,
+                                                             int32_t *__restrict__ positions, long long cap)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int lo = 0, cnt = 0;
+    long long off = 0;
+    if (g < S) {
+        lo = lohi[g * stride];
+        const int hi = lohi[g * stride + 1];
+        cnt = (lo >= 0 && hi >= lo) ? hi - lo + 1 : 0;
+        off = offsets[g];
+    }
+    const bool big = cnt > 32;
+    if (!big)
+        for (int i = 0; i < cnt; i++)
+            if (off + i < cap) positions[off + i] = ix.sa[lo + i].s + 1;
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int blo = __shfl(lo, src), bcnt = __shfl(cnt, src);
+        const long long boff = __shfl(off, src);
+        for (int i = lane; i < bcnt; i += kWave)
+            if (boff + i < cap) positions[boff + i] = ix.sa[blo + i].s + 1;
+    }
+}
+
+}  // namespace
+
+int64_t locate_tmp_bytes(int64_t S) { return ws_align(S * 4) + ws_align(compact_tmp_bytes(S)) + 256; }
+
+int launch_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_offsets,
+                  int32_t *d_positions, int64_t cap, void *d_tmp, int64_t tmp_bytes, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (S == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, s));
+        return GENIE_OK;
+    }
+    if (!d_tmp || tmp_bytes < locate_tmp_bytes(S) || (reinterpret_cast<uintptr_t>(d_tmp) & 255) != 0) return GENIE_E_CAPACITY;
+    int32_t *counts = reinterpret_cast<int32_t *>(d_tmp);
+    void *scan_tmp = reinterpret_cast<uint8_t *>(d_tmp) + ws_align(S * 4);
+    const unsigned grid = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(locate_count_kernel, dim3(grid), dim3(256), 0, s, d_lohi, stride, (long long)S, counts);
+    int rc = launch_compact(counts, nullptr, S, 0x7FFFFFFF, d_offsets, nullptr, 0, scan_tmp, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(locate_scatter_kernel, dim3(grid), dim3(256), 0, s, ix->dev, d_lohi, stride, (long long)S,
+                       reinterpret_cast<const long long *>(d_offsets), d_positions, (long long)cap);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -175,6 +175,22 @@ class ExactMatch:
             lens[i] = len(e)
         return self.index(self._any_k()).sa_interval(mat, lens).cpu().numpy()
 
+    def exact_match_positions_batch(self, patterns):
+        """Batched exact_match (ExactMatch.py:174-192): for every pattern the ascending 1-based
+        positions of its occurrences ([] if absent), resolved on the device (genie_sa_interval +
+        genie_locate)."""
+        enc = [self.encode(p) for p in patterns]
+        width = max([len(e) for e in enc] + [1])
+        mat = np.zeros((len(enc), width), np.uint8)
+        lens = np.zeros(len(enc), np.int32)
+        for i, e in enumerate(enc):
+            mat[i, :len(e)] = e
+            lens[i] = len(e)
+        ix = self.index(self._any_k())
+        off, pos = ix.locate(ix.sa_interval(mat, lens), sort=True)
+        off, pos = off.cpu().numpy(), pos.cpu().numpy()
+        return [pos[off[i]:off[i + 1]].tolist() for i in range(len(enc))]
+
     def exact_match_back_prop_add_one(self, char, prev_suffix_tuple):
         """ExactMatch.py:155-171: one backward-search step.  Host-side helper (not used by the
         batched path): rows of `char`'s bucket are ordered by the rank of the suffix that follows,

@@ -234,6 +234,38 @@ class GenieIndex:
                                                 out.shape[0], _ptr(tmp), st), "genie_compact_smems")
         return offsets, out
 
+    def locate(self, intervals, sort=False):
+        """Rows -> reference coordinates for a batch of SA intervals (ExactMatch.get_positions,
+        ExactMatch.py:195-199): `intervals` is int32 [S, 2] (lo, hi) -- a sa_interval result -- or
+        int32 [S, 4] (start, end, lo, hi) -- find_smems rows.  Returns (pos_offsets int64[S+1],
+        positions int32[T]): 1-based positions in row order, or ascending per interval with sort=True
+        (ExactMatch.exact_match's order, :174-192)."""
+        self._need_device()
+        iv = self._as_dev(intervals, torch.int32)
+        if iv.dim() != 2 or iv.shape[1] not in (2, 4):
+            raise ValueError("intervals must be [S, 2] (lo, hi) or [S, 4] (start, end, lo, hi)")
+        iv = iv.contiguous()
+        S, width = iv.shape
+        offsets = torch.empty(S + 1, dtype=torch.int64, device=self.device)
+        tmp_bytes = int(N.lib().genie_locate_tmp_bytes(S))
+        tmp = torch.empty(max(tmp_bytes, 256), dtype=torch.uint8, device=self.device)
+        base = iv.data_ptr() + (8 if width == 4 else 0)
+        with torch.cuda.device(self.device):
+            st = _stream(self.device)
+            N.check(N.lib().genie_locate(self._h, C.c_void_p(base), width, S, _ptr(offsets), C.c_void_p(0), 0, _ptr(tmp),
+                                         tmp_bytes, st), "genie_locate")
+            total = int(offsets[-1].item())
+            pos = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
+            N.check(N.lib().genie_locate(self._h, C.c_void_p(base), width, S, _ptr(offsets), _ptr(pos), total, _ptr(tmp),
+                                         tmp_bytes, st), "genie_locate")
+        pos = pos[:total]
+        if sort and total:
+            # ascending inside every interval: one sort on (interval, position) keys -- torch plumbing
+            seg = torch.repeat_interleave(torch.arange(S, device=self.device), offsets[1:] - offsets[:-1])
+            key = seg * (int(self.info()["n"]) + 2) + pos.to(torch.int64)
+            pos = pos[torch.argsort(key)]
+        return offsets, pos
+
     def find_smems(self, mode, reads, lens=None, min_len=1, cap=None, rows_hint=None):
         """Batched SMEM discovery -> (offsets int64[N+1], smems int32[S,4] = (start,end,lo,hi), status).
         Uses the fused CSR entry point (genie_find_smems_csr) unless an explicit slot capacity is asked for."""

@@ -184,6 +184,18 @@ int64_t genie_compact_tmp_bytes(int64_t N);
 int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap,
                         int64_t *d_offsets, int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
 
+/* Rows -> reference coordinates: ExactMatch.get_positions (SMEM/ExactMatch.py:195-199) for S intervals at
+ * once.  Interval t is (d_lohi[t*stride], d_lohi[t*stride + 1]) = inclusive rows (lo, hi); lo < 0 or
+ * hi < lo (absent) contributes nothing.  Pass the (lo, hi) columns of a find_smems result as
+ * d_rows + 2 with stride 4, or a genie_sa_interval result with stride 2.  Output CSR:
+ * d_pos_offsets[S+1], d_positions[...] = the suffix-array entries of rows lo..hi, 1-based like the
+ * reference's, in row order (ExactMatch.exact_match sorts them: :174-192).  Entries beyond cap_positions
+ * are dropped (compare d_pos_offsets[S] with the capacity).  d_tmp: 256-byte aligned scratch of
+ * genie_locate_tmp_bytes(S) bytes. */
+int64_t genie_locate_tmp_bytes(int64_t S);
+int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_pos_offsets,
+                 int32_t *d_positions, int64_t cap_positions, void *d_tmp, int64_t tmp_bytes, void *stream);
+
 /* Launch-time options of an index handle.
  * GENIE_OPT_LUT_PROBE (default 0): in LUT mode on the short-read path, also probe the K-mer hash
  * table for every read position before the suffix-array search.  Results are identical either

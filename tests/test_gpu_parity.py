@@ -343,6 +343,51 @@ def test_absent_base_is_flagged(pkg):
         pkg.SMEM(m, lut_size=2).get_SMEMS("ACAGAC", 1)
 
 
+# ------------------------------------------------------------------ rows -> coordinates
+def test_locate_positions(pkg):
+    """genie_locate == ExactMatch.get_positions (suffix-array entries of rows lo..hi, 1-based, row order)
+    for SMEM rows, absent intervals, and intervals of thousands of rows (short patterns); the sorted
+    form == ExactMatch.exact_match, pinned by the reference's mississippi answers."""
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load("big100k_K15")
+    ix = _index(pkg, "big100k_K15")
+    sa = ix.suffix_array().astype(np.int64)
+    rd = B.reads_from_ref(d["ref_codes"], 500, 150, 11)
+    offsets, smems, st = ix.find_smems("lut", rd)
+    po, pos = ix.locate(smems)
+    po, pos, sm = po.cpu().numpy(), pos.cpu().numpy(), smems.cpu().numpy()
+    assert po[0] == 0 and po[-1] == len(pos) == int((sm[:, 3] - sm[:, 2] + 1).sum())
+    for t in range(0, len(sm), 7):
+        assert pos[po[t]:po[t + 1]].tolist() == sa[sm[t, 2]:sm[t, 3] + 1].tolist()
+    # short patterns: wide intervals (whole-wave copies), the empty pattern, absent ones
+    pats = np.zeros((40, 12), np.uint8)
+    lens = np.asarray([0, 1, 1, 1, 1, 2, 2, 3, 3, 4] + [12] * 30, np.int32)
+    rng = np.random.default_rng(5)
+    pats[:] = rng.integers(0, 4, pats.shape)
+    iv = ix.sa_interval(pats, lens)
+    po, pos = ix.locate(iv)
+    po, pos, ivh = po.cpu().numpy(), pos.cpu().numpy(), iv.cpu().numpy()
+    assert ivh[0].tolist() == [0, len(d["ref_codes"])] and (ivh[10:, 0] == -1).any()
+    for t in range(40):
+        lo, hi = ivh[t]
+        want = sa[lo:hi + 1].tolist() if lo >= 0 else []
+        assert pos[po[t]:po[t + 1]].tolist() == want, t
+    _, spos = ix.locate(iv, sort=True)
+    spos = spos.cpu().numpy()
+    for t in range(40):
+        assert spos[po[t]:po[t + 1]].tolist() == sorted(pos[po[t]:po[t + 1]].tolist())
+    assert ix.locate(torch.empty((0, 2), dtype=torch.int32))[0].tolist() == [0]
+    # the reference's own answers
+    k = G.known()["mississippi"]
+    m = pkg.ExactMatch("mississippi.fa")
+    m.set_reference(k["ref"])
+    pats = sorted(k["exact_match"])
+    got = m.exact_match_positions_batch(pats + ["ppp", "mississippi"])
+    assert got[:len(pats)] == [k["exact_match"][p_] for p_ in pats] and got[-2] == [] and got[-1] == [1]
+    assert all(m.exact_match(p_) == k["exact_match"][p_] for p_ in pats)
+
+
 # ------------------------------------------------------------------ 1 Mb reference (BASELINE configs 3-4 shape)
 def test_one_megabase_reference(pkg, oracle_mod):
     """REF_1M (seed 1 000 000), K = 15, natively trained RMI [1000]: the three modes against the CPU
