@@ -30,7 +30,7 @@ SYMBOLS = [
     "genie_index_serialize", "genie_index_open", "genie_index_to_device", "genie_index_destroy",
     "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_csr", "genie_find_smems_workspace_bytes",
     "genie_compact_tmp_bytes",
-    "genie_compact_smems", "genie_locate_tmp_bytes", "genie_locate", "genie_launch_info", "genie_index_set_option", "genie_index_set_stage_events", "genie_strerror", "genie_last_hip_error",
+    "genie_compact_smems", "genie_locate_tmp_bytes", "genie_locate", "genie_index_train_rmi", "genie_index_rmi_models", "genie_launch_info", "genie_index_set_option", "genie_index_set_stage_events", "genie_strerror", "genie_last_hip_error",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
         "genie_find_smems_workspace_bytes": (i64, [i64, i32]),
         "genie_compact_tmp_bytes": (i64, [i64]),
         "genie_compact_smems": (C.c_int, [vp, vp, i64, i32, vp, vp, i64, vp, vp]),
+        "genie_index_train_rmi": (C.c_int, [vp, i32, vp, vp, vp]),
+        "genie_index_rmi_models": (C.c_int, [vp, vp, vp, vp]),
         "genie_locate_tmp_bytes": (i64, [i64]),
         "genie_locate": (C.c_int, [vp, vp, i32, i64, vp, vp, i64, vp, i64, vp]),
         "genie_launch_info": (C.c_int, [vp, i32, i32, i32p, i32p, i32p]),

@@ -82,7 +82,33 @@ int genie_index_set_rmi(genie_index *ix, int32_t nlev, const int32_t *sizes, con
     for (int l = nlev; l <= GENIE_MAX_RMI_LEVELS; l++) h.rmi_off[l] = (int32_t)tot;
     h.rmi.resize((size_t)tot);
     for (int64_t i = 0; i < tot; i++) h.rmi[(size_t)i] = RmiModel{coef[i], icpt[i]};
+    h.rmi_err.clear();                       // error bounds belong to a natively trained model
     fill_header(h, &ix->hdr);
+    return GENIE_OK;
+}
+
+int genie_index_train_rmi(genie_index *ix, int32_t n_experts, const int32_t *experts, double *mean_abs_err,
+                          int32_t *max_abs_err)
+{
+    if (!ix || !ix->host || ix->has_dev || (n_experts > 0 && !experts)) return GENIE_E_INVALID;
+    int rc = train_rmi(*ix->host, n_experts, experts, mean_abs_err, max_abs_err);
+    if (rc) return rc;
+    fill_header(*ix->host, &ix->hdr);
+    return GENIE_OK;
+}
+
+int genie_index_rmi_models(const genie_index *ix, double *coef, double *icpt, int32_t *leaf_err)
+{
+    if (!ix || !ix->host || ix->host->nlev < 1) return GENIE_E_INVALID;
+    const HostIndex &h = *ix->host;
+    for (size_t i = 0; i < h.rmi.size(); i++) {
+        if (coef) coef[i] = h.rmi[i].coef;
+        if (icpt) icpt[i] = h.rmi[i].icpt;
+    }
+    if (leaf_err) {
+        if (h.rmi_err.empty()) return GENIE_E_INVALID;
+        for (size_t i = 0; i < h.rmi_err.size(); i++) leaf_err[i] = h.rmi_err[i];
+    }
     return GENIE_OK;
 }
 

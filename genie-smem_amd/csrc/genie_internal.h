@@ -14,7 +14,7 @@ struct uint2 { unsigned int x, y; };
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 4;
+constexpr uint32_t kBlobVersion = 5;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -93,6 +93,8 @@ struct BlobHeader {
     int64_t dir2_entries;
     int32_t P2;           // 0 = no second-level table
     int32_t pad2;
+    int64_t off_rmi_err;  // int32 [rmi_err_entries]: per leaf model, max |int(prediction) - row| over the training keys
+    int64_t rmi_err_entries;   // 0 = no error table (model installed from coefficients)
 };
 // The serialized header occupies GENIE_HEADER_BYTES; the struct is copied into its front.
 static_assert(sizeof(BlobHeader) <= GENIE_HEADER_BYTES, "header size");
@@ -105,6 +107,7 @@ struct DevIndex {
     const LutSlot *lut;
     const RmiModel *rmi;
     const HeadRec *dir2;   // second-level range table (global, L2-resident), or null
+    const int32_t *rmi_err; // per-leaf error bounds of a natively trained RMI, or null
     int32_t n;
     int32_t K;
     int32_t P;
@@ -142,6 +145,7 @@ struct HostIndex {
     int32_t rmi_scale[GENIE_MAX_RMI_LEVELS] = {0, 0, 0, 0};
     int32_t rmi_off[GENIE_MAX_RMI_LEVELS + 1] = {0, 0, 0, 0, 0};
     std::vector<RmiModel> rmi;
+    std::vector<int32_t> rmi_err;        // per leaf model (native training only)
 };
 
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
@@ -185,6 +189,7 @@ int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, i
                    int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
 int64_t compact_tmp_bytes(int64_t N);
 int64_t locate_tmp_bytes(int64_t S);
+int train_rmi(HostIndex &h, int n_experts, const int32_t *experts, double *mean_abs_err, int32_t *max_abs_err);
 int launch_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_offsets,
                   int32_t *d_positions, int64_t cap, void *d_tmp, int64_t tmp_bytes, void *stream);
 int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,

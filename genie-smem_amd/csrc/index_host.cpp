@@ -266,7 +266,146 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     off = align_up(off + (int64_t)std::max<size_t>(h.rmi.size(), 1) * (int64_t)sizeof(RmiModel));
     hdr->off_dir2 = off;
     off = align_up(off + (int64_t)std::max<size_t>(h.dir2.size(), 1) * (int64_t)sizeof(HeadRec));
+    hdr->off_rmi_err = off;
+    hdr->rmi_err_entries = (int64_t)h.rmi_err.size();
+    off = align_up(off + (int64_t)std::max<size_t>(h.rmi_err.size(), 1) * 4);
     hdr->total_bytes = off;
+}
+
+// ------------------------------------------------------------------ native RMI training
+// RMI_LUT.train_RMI (RMI_LUT.py:36-50) + RMI.fit (RMI.py:10-50) without scikit-learn: the
+// (K-mer code, SA row) pairs of every row whose suffix holds a full K-mer, in SA order; per level and
+// per non-empty expert the closed-form least-squares line to the reference's bucket-budget target
+// (RMI.py:29-39); points routed with the reference's clamp(int(p)) (RMI.py:42-46); empty experts alias
+// the root model (RMI.py:24-26).  Also records, per leaf model, the largest |int(prediction) - row|
+// over the training pairs: a window of that radius around a prediction holds every row of any K-mer
+// that occurs in the reference, which bounds the last-mile search.
+namespace {
+struct Line { double coef, icpt; };
+
+Line fit_line(const std::vector<double> &x, const std::vector<double> &y)
+{
+    const size_t m = x.size();
+    long double sx = 0, sy = 0;
+    for (size_t i = 0; i < m; i++) { sx += x[i]; sy += y[i]; }
+    const double xm = (double)(sx / m), ym = (double)(sy / m);
+    long double var = 0, cov = 0;
+    for (size_t i = 0; i < m; i++) {
+        const long double dx = (long double)x[i] - xm;
+        var += dx * dx;
+        cov += dx * ((long double)y[i] - ym);
+    }
+    const double slope = var > 0 ? (double)(cov / var) : 0.0;
+    return Line{slope, ym - slope * xm};
+}
+
+inline int64_t route(double p, int scale)
+{
+    if (!(p > 0.0)) return 0;
+    if (p >= (double)scale) return scale - 1;
+    return (int64_t)p;
+}
+}  // namespace
+
+int train_rmi(HostIndex &h, int n_experts, const int32_t *experts, double *mean_abs_err, int32_t *max_abs_err)
+{
+    const int nlev = n_experts + 1;
+    if (n_experts < 0 || nlev > GENIE_MAX_RMI_LEVELS || h.K < 1 || h.n < h.K) return GENIE_E_INVALID;
+    for (int l = 0; l < n_experts; l++)
+        if (experts[l] < 1 || experts[l] > (1 << 24)) return GENIE_E_INVALID;
+    const int64_t rows = h.n + 1;
+    std::vector<double> x, y;
+    x.reserve((size_t)rows);
+    y.reserve((size_t)rows);
+    for (int64_t r = 0; r < rows; r++) {
+        const int64_t s = h.sa0[(size_t)r];
+        if (h.n - s < h.K) continue;
+        x.push_back((double)code_at64(h.codes.data(), s, h.K));
+        y.push_back((double)r);
+    }
+    const size_t m = x.size();
+    if (m == 0) return GENIE_E_INVALID;
+    std::vector<int32_t> scales(nlev), sizes(nlev);
+    for (int l = 0; l < nlev; l++) {
+        scales[l] = l < n_experts ? experts[l] : 1;
+        sizes[l] = l == 0 ? 1 : scales[l - 1];
+    }
+    std::vector<std::vector<Line>> models(nlev);
+    std::vector<int32_t> assign(m, 0), nxt(m, 0);
+    std::vector<double> cx, cy;
+    for (int l = 0; l < nlev; l++) {
+        const int nb = sizes[l], scale = scales[l];
+        // stable counting sort of the points by expert
+        std::vector<int64_t> bounds((size_t)nb + 1, 0);
+        for (size_t i = 0; i < m; i++) bounds[(size_t)assign[i] + 1]++;
+        for (int b = 0; b < nb; b++) bounds[(size_t)b + 1] += bounds[(size_t)b];
+        std::vector<int64_t> order(m), fill(bounds.begin(), bounds.end() - 1);
+        for (size_t i = 0; i < m; i++) order[(size_t)fill[(size_t)assign[i]]++] = (int64_t)i;
+        models[l].resize((size_t)nb);
+        double allocated = 0.0;
+        for (int b = 0; b < nb; b++) {
+            const int64_t b0 = bounds[(size_t)b], b1 = bounds[(size_t)b + 1];
+            if (b0 == b1) { models[l][(size_t)b] = models[0][0]; continue; }        // RMI.py:24-26
+            cx.clear();
+            cy.clear();
+            double ymin = 1e300, ymax = -1e300;
+            for (int64_t t = b0; t < b1; t++) {
+                const size_t i = (size_t)order[(size_t)t];
+                cx.push_back(x[i]);
+                cy.push_back(y[i]);
+                ymin = std::min(ymin, y[i]);
+                ymax = std::max(ymax, y[i]);
+            }
+            if (l < nlev - 1) {                                                     // RMI.py:29-39
+                const double span = ymax - ymin;
+                double budget = 1.0;
+                if (span != 0.0) {
+                    for (double &v : cy) v = (v - ymin) / span;
+                    budget = (double)(b1 - b0) * (double)scale / (double)m;
+                }
+                for (double &v : cy) v = v * budget + allocated;
+                allocated += budget;
+            }
+            const Line ln = fit_line(cx, cy);
+            models[l][(size_t)b] = ln;
+            for (int64_t t = b0; t < b1; t++) {
+                const size_t i = (size_t)order[(size_t)t];
+                nxt[i] = (int32_t)route(ln.coef * x[i] + ln.icpt, scale);            // one rounding each, no FMA
+            }
+        }
+        // which leaf model serves a point = its expert at the last level
+        if (l < nlev - 1) assign.swap(nxt);
+    }
+    // install (the layout genie_index_set_rmi produces) + per-leaf error bounds
+    h.nlev = nlev;
+    int64_t off = 0;
+    for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
+        h.rmi_size[l] = l < nlev ? sizes[l] : 0;
+        h.rmi_scale[l] = l < nlev ? scales[l] : 0;
+        h.rmi_off[l] = (int32_t)off;
+        if (l < nlev) off += sizes[l];
+    }
+    for (int l = nlev; l <= GENIE_MAX_RMI_LEVELS; l++) h.rmi_off[l] = (int32_t)off;
+    h.rmi.clear();
+    for (int l = 0; l < nlev; l++)
+        for (const Line &ln : models[l]) h.rmi.push_back(RmiModel{ln.coef, ln.icpt});
+    const int nleaf = sizes[nlev - 1];
+    h.rmi_err.assign((size_t)nleaf, 0);
+    long double tot = 0;
+    int32_t worst = 0;
+    for (size_t i = 0; i < m; i++) {
+        const int leaf = assign[i];
+        const Line &ln = models[nlev - 1][(size_t)leaf];
+        const double p = ln.coef * x[i] + ln.icpt;
+        const int64_t r0 = !(p > 0.0) ? 0 : (p >= (double)rows ? rows - 1 : (int64_t)p);    // int(start_sa), clamped
+        const int64_t e = r0 > (int64_t)y[i] ? r0 - (int64_t)y[i] : (int64_t)y[i] - r0;
+        if (e > h.rmi_err[(size_t)leaf]) h.rmi_err[(size_t)leaf] = (int32_t)e;
+        if (e > worst) worst = (int32_t)e;
+        tot += (long double)e;
+    }
+    if (mean_abs_err) *mean_abs_err = (double)(tot / m);
+    if (max_abs_err) *max_abs_err = worst;
+    return GENIE_OK;
 }
 
 int serialize(const HostIndex &h, void *dst, int64_t cap)
@@ -283,6 +422,7 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
     if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
     if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * sizeof(HeadRec));
+    if (!h.rmi_err.empty()) memcpy(p + hdr.off_rmi_err, h.rmi_err.data(), h.rmi_err.size() * 4);
     return GENIE_OK;
 }
 
@@ -303,6 +443,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->rmi = (const RmiModel *)(p + hdr.off_rmi);
     out->dir2 = hdr.P2 > 0 ? (const HeadRec *)(p + hdr.off_dir2) : nullptr;
     out->P2 = hdr.P2;
+    out->rmi_err = hdr.rmi_err_entries > 0 ? (const int32_t *)(p + hdr.off_rmi_err) : nullptr;
     out->n = (int32_t)hdr.n;
     out->K = hdr.K;
     out->P = hdr.P;

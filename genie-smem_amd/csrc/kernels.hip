@@ -219,12 +219,14 @@ __device__ __forceinline__ bool lut_probe(const DevIndex &ix, uint32_t code, int
 // RMI.predict for one key (SMEM/RMI.py:52-69): per level p = coef*x + intercept, rounded after
 // the multiply and after the add (sklearn computes X @ coef_ + intercept_), next expert =
 // min(scale-1, max(0, int(p))).  `leaf` = the first `leaf_cnt` models of the last level staged in LDS (or nullptr).
-__device__ __forceinline__ double rmi_predict(const DevIndex &ix, const RmiModel *leaf, int leaf_cnt, uint32_t code)
+__device__ __forceinline__ double rmi_predict(const DevIndex &ix, const RmiModel *leaf, int leaf_cnt, uint32_t code,
+                                              int *leaf_idx = nullptr)
 {
     const double x = (double)code;
     double p = 0.0;
     int idx = 0;
     for (int l = 0; l < ix.nlev; l++) {
+        if (leaf_idx && l == ix.nlev - 1) *leaf_idx = idx;
         double2 m;
         if (leaf && l == ix.nlev - 1 && idx < leaf_cnt) m = *reinterpret_cast<const double2 *>(leaf + idx);   // LDS
         else m = *reinterpret_cast<const double2 *>(ix.rmi + ix.rmi_off[l] + idx);               // global
@@ -258,12 +260,32 @@ __device__ __forceinline__ int kmer_cmp_row(const DevIndex &ix, int r, uint32_t 
 __device__ __forceinline__ bool rmi_lookup(const DevIndex &ix, const RmiModel *leaf, uint32_t code, int &lo, int &hi,
                                            double *pred_out)
 {
-    const double p = rmi_predict(ix, leaf, 0, code);
+    int leaf_idx = 0;
+    const double p = rmi_predict(ix, leaf, 0, code, &leaf_idx);
     if (pred_out) *pred_out = p;
     const int rows = ix.n + 1;
     const int r0 = !(p > 0.0) ? 0 : (p >= (double)rows ? rows - 1 : (int)p);     // int(start_sa), clamped
     // bracket the first row that is not smaller than the K-mer: rows < L are smaller, row R is not
     int L, R;
+    bool fenced = false;
+    if (ix.rmi_err) {
+        // natively trained model: every row of a K-mer that occurs lies within the leaf's error bound of
+        // the prediction, so one window replaces the doubling probes.  A K-mer that does not occur may
+        // fall outside it; that case is recognised below and redone with the galloping bracket.
+        const int e = ix.rmi_err[leaf_idx];
+        L = r0 - e < 0 ? 0 : r0 - e;
+        R = r0 + e + 1 > rows ? rows : r0 + e + 1;
+        int l2 = L, r2 = R;
+        while (l2 < r2) {
+            const int mid = (l2 + r2) >> 1;
+            if (kmer_cmp_row(ix, mid, code) < 0) l2 = mid + 1; else r2 = mid;
+        }
+        if (l2 < rows && kmer_cmp_row(ix, l2, code) == 0 && (l2 > L || L == 0 || kmer_cmp_row(ix, l2 - 1, code) < 0)) {
+            L = R = l2;
+            fenced = true;
+        }
+    }
+    if (!fenced) {
     if (kmer_cmp_row(ix, r0, code) < 0) {
         L = r0 + 1;
         R = rows;
@@ -282,6 +304,7 @@ __device__ __forceinline__ bool rmi_lookup(const DevIndex &ix, const RmiModel *l
             if (kmer_cmp_row(ix, pr, code) < 0) { L = pr + 1; break; }
             R = pr;
         }
+    }
     }
     while (L < R) {
         const int mid = (L + R) >> 1;

@@ -72,6 +72,27 @@ class GenieIndex:
                                             icpt.ctypes.data_as(dp)), "genie_index_set_rmi")
         self._host_blob = None
 
+    def train_rmi(self, experts):
+        """Native RMI training (genie_index_train_rmi; RMI_LUT.train_RMI + RMI.fit without scikit-learn).
+        Returns (coefs, icpts, leaf_err, mean_abs_err, max_abs_err): per-level float64 arrays, the
+        per-leaf error bounds, and the error statistics over the training pairs."""
+        ex = np.asarray(list(experts), np.int32)
+        mean = C.c_double(0.0)
+        worst = C.c_int32(0)
+        N.check(N.lib().genie_index_train_rmi(self._h, len(ex), ex.ctypes.data_as(C.c_void_p), C.byref(mean),
+                                              C.byref(worst)), "genie_index_train_rmi")
+        self._host_blob = None
+        sizes = [1] + [int(e) for e in ex]
+        coef = np.empty(sum(sizes), np.float64)
+        icpt = np.empty(sum(sizes), np.float64)
+        err = np.empty(sizes[-1], np.int32)
+        N.check(N.lib().genie_index_rmi_models(self._h, coef.ctypes.data_as(C.c_void_p), icpt.ctypes.data_as(C.c_void_p),
+                                               err.ctypes.data_as(C.c_void_p)), "genie_index_rmi_models")
+        cuts = np.cumsum([0] + sizes)
+        coefs = [coef[cuts[i]:cuts[i + 1]].copy() for i in range(len(sizes))]
+        icpts = [icpt[cuts[i]:cuts[i + 1]].copy() for i in range(len(sizes))]
+        return coefs, icpts, err, float(mean.value), int(worst.value)
+
     def info(self):
         inf = N.GenieInfo()
         N.check(N.lib().genie_index_info(self._h, C.byref(inf)), "genie_index_info")

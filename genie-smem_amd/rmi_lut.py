@@ -34,10 +34,23 @@ class RMI_LUT:
     def suffix_array(self):
         return self.matcher.host_index(self.prediction_size).suffix_array()
 
-    def train_RMI(self):
+    def train_RMI(self, native=True):
         """RMI_LUT.py:36-50: (K-mer code, SA row) pairs for every row whose suffix holds a full
-        K-mer, in SA order; then RMI.fit."""
+        K-mer, in SA order; then RMI.fit.  native=True (default): the C++ trainer behind
+        genie_index_train_rmi, which also records per-leaf error bounds for the device's last-mile
+        search; native=False: the numpy restatement in rmi.py."""
         K = self.prediction_size
+        if native:
+            ix = self.matcher.host_index(K)
+            if ix.blob is not None:                      # image already uploaded: train on a fresh host handle
+                self.matcher._indexes.pop(K)
+                ix = self.matcher.host_index(K)
+            coefs, icpts, err, mean, worst = ix.train_rmi(self.structure)
+            self.rmi = RMI.from_coefficients(self.structure, coefs, icpts)
+            self.leaf_error = err
+            self.fit_error = (mean, worst)
+            self._installed = True
+            return
         sa = np.asarray(self.suffix_array, np.int64)
         rows = np.nonzero(sa - 1 + K <= self.ref_seq_size)[0]
         codes = self.matcher._codes.astype(np.int64)

@@ -104,6 +104,19 @@ int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *s
 int genie_index_set_rmi(genie_index *ix, int32_t nlev, const int32_t *sizes, const int32_t *scales,
                         const double *coef, const double *icpt);
 
+/* Train the RMI natively (no scikit-learn): RMI_LUT.train_RMI + RMI.fit (SMEM/RMI_LUT.py:36-50,
+ * SMEM/RMI.py:10-50) on the handle's own (K-mer code, SA row) pairs, `experts` as in
+ * RMI_LUT(structure=experts, ...), e.g. {1000} or {10, 100}; closed-form least squares per expert with
+ * the reference's bucket-budget targets.  Installs the model like genie_index_set_rmi and also records a
+ * per-leaf error bound (max |int(prediction) - row| over the training pairs) that the device uses to
+ * fence the last-mile search of genie_seed_lookup.  Outputs (optional): mean and max of that error.
+ * Coefficients differ from scikit-learn's in the last bits, which only moves where a search starts. */
+int genie_index_train_rmi(genie_index *ix, int32_t n_experts, const int32_t *experts, double *mean_abs_err,
+                          int32_t *max_abs_err);
+/* Export the installed model: coef / icpt hold all levels concatenated (1 + experts[0] + ... entries);
+ * leaf_err (optional, natively trained models only) one bound per model of the last level. */
+int genie_index_rmi_models(const genie_index *ix, double *coef, double *icpt, int32_t *leaf_err);
+
 int genie_index_info(const genie_index *ix, genie_info *out);
 
 /* Host views for the position-resolution helpers of the drop-in API

@@ -217,6 +217,26 @@ def test_rmi_predict_bit_exact_and_true_interval(pkg, ds):
         assert (lohi[ok & ~absent] == ref[ok & ~absent]).all()
 
 
+def test_native_rmi_fenced_lookup(pkg):
+    """A natively trained RMI carries per-leaf error bounds and genie_seed_lookup fences its last-mile
+    search with them: every K-mer of the reference gets its true rows, absent K-mers keep lower > upper
+    and the same values as the unfenced search."""
+    d, _ = G.load("big100k_K15")
+    ref = d["ref_codes"]
+    ix = pkg.GenieIndex.build(ref, 15)
+    ix.train_rmi([1000])
+    codes, lo, hi = ix.lut_arrays()
+    ix = ix.to("cuda")
+    kmers = ((codes[:, None].astype(np.int64) >> (2 * np.arange(14, -1, -1))) & 3).astype(np.uint8)
+    got = ix.seed_lookup("rmi", kmers).cpu().numpy()
+    assert (got[:, 0] == lo).all() and (got[:, 1] == hi).all()
+    rng = np.random.default_rng(9)
+    rnd = rng.integers(0, 4, (20000, 15)).astype(np.uint8)
+    plain = _index(pkg, "big100k_K15", _rmi_tag("big100k_K15"))          # fixture coefficients: no error table
+    a, b = ix.seed_lookup("rmi", rnd).cpu().numpy(), plain.seed_lookup("rmi", rnd).cpu().numpy()
+    assert (a == b).all() and (a[:, 0] > a[:, 1]).sum() > 19000
+
+
 def test_dropin_rmi_lut(pkg):
     d, _ = G.load("syn10k_K8")
     m = pkg.ExactMatch("syn10k.fa")

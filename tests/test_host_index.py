@@ -117,7 +117,7 @@ def test_reference_checked_in_fixtures(pkg):
 
 
 # ------------------------------------------------------------------ image + prefix directory
-HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqii")
+HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqiiqq")
 
 
 def _parse(img):
@@ -125,8 +125,9 @@ def _parse(img):
     keys = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
             "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
     h = dict(zip(keys, f[:18]))
-    h["padtail"] = list(f[-12:-4])
-    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-4], f[-3], f[-2]
+    h["padtail"] = list(f[-14:-6])
+    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-6], f[-5], f[-4]
+    h["off_rmi_err"], h["rmi_err_entries"] = f[-2], f[-1]
     return h
 
 
@@ -228,6 +229,42 @@ def test_rmi_fit_is_a_usable_model(pkg):
     # scalar API shape: array of one float64, like the reference's rmi_predict
     q = G.codes_to_str(d["ref_codes"][100:108])
     assert r.rmi_predict(q).shape == (1,)
+
+
+def test_native_rmi_training(pkg):
+    """genie_index_train_rmi (C++) against the numpy restatement of RMI.fit on the same pairs: same
+    structure, near-identical predictions, and leaf error bounds that do bound every training pair."""
+    d, _ = G.load("syn100k_K15")
+    ref, K = d["ref_codes"], 15
+    for experts in ([1000], [10, 100], []):
+        ix = pkg.GenieIndex.build(ref, K)
+        coefs, icpts, err, mean, worst = ix.train_rmi(experts)
+        assert [len(c) for c in coefs] == [1] + list(experts) and len(err) == ([1] + list(experts))[-1]
+        sa0 = ix.suffix_array().astype(np.int64) - 1
+        rows = np.nonzero(sa0 + K <= len(ref))[0]
+        key = np.zeros(len(rows), np.int64)
+        for j in range(K):
+            key = (key << 2) | ref[sa0[rows] + j]
+        native = pkg.RMI.from_coefficients(experts, coefs, icpts)
+        ref_fit = pkg.RMI(list(experts)).fit(key.reshape(-1, 1), rows)
+        p_nat, p_np = native.predict(key), ref_fit.predict(key)
+        # the two fits differ in summation order only: predictions agree to a fraction of a row almost everywhere
+        assert np.median(np.abs(p_nat - p_np)) < 1e-3
+        e = np.abs(np.clip(np.trunc(p_nat), 0, len(ref)).astype(np.int64) - rows)
+        assert abs(e.mean() - mean) < 1e-9 and e.max() == worst
+        # leaf of every pair, by replaying the routing
+        idx = np.zeros(len(key), np.int64)
+        x = key.astype(np.float64)
+        for lvl, scale in enumerate(list(experts)):
+            p = x * coefs[lvl][idx] + icpts[lvl][idx]
+            idx = np.minimum(scale - 1, np.maximum(0, np.trunc(p))).astype(np.int64)
+        assert (e <= err[idx]).all()
+        h = _parse(ix.serialize().numpy())
+        assert h["rmi_err_entries"] == len(err) and h["nlev"] == len(experts) + 1
+    # coefficients installed from outside carry no error table
+    ix = pkg.GenieIndex.build(ref[:20000], K)
+    ix.set_rmi([], [np.asarray([1e-5])], [np.asarray([0.0])])
+    assert _parse(ix.serialize().numpy())["rmi_err_entries"] == 0
 
 
 def test_second_level_range_table(pkg):
