@@ -219,7 +219,7 @@ int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
 
 /* Profiling hook: two hipEvent_t (as void*, created by the caller with timing enabled) that the next
  * genie_find_smems calls record on their stream immediately before and after the dominant kernel of
- * the path (the suffix-array search: match_stats_kernel, or find_smems_kernel for reads > 255 bp).
+ * the path (the suffix-array search, match_stats_kernel).
  * Pass NULLs to stop.  Not thread-safe with concurrent launches on the same handle. */
 int genie_index_set_stage_events(genie_index *ix, void *ev_search_begin, void *ev_search_end);
 

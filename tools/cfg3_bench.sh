@@ -1,8 +1,7 @@
 mkdir -p gpurun_out/cfg3
-for v in $AB_DIR2; do
-  GENIE_DIR2_BITS=$v timeout -k 10 400 python bench.py --config 3 --reads 2000000 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/cfg3/rmi_p2_$v.json 2> gpurun_out/cfg3/rmi_p2_$v.err || exit 1
-  GENIE_DIR2_BITS=$v timeout -k 10 400 python bench.py --config 3 --mode lut --reads 2000000 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/cfg3/lut_p2_$v.json 2> gpurun_out/cfg3/lut_p2_$v.err || exit 1
-done
+for v in $AB_DIR2; do for m in $MODES; do
+  GENIE_DIR2_BITS=$v timeout -k 10 500 python bench.py --config 3 --mode $m --reads $READS --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/cfg3/${m}_p2_$v.json 2> gpurun_out/cfg3/${m}_p2_$v.err || exit 1
+done; done
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/cfg3/*.json")):
