@@ -363,6 +363,57 @@ def test_absent_base_is_flagged(pkg):
         pkg.SMEM(m, lut_size=2).get_SMEMS("ACAGAC", 1)
 
 
+# ------------------------------------------------------------------ multi-GPU plumbing on one GPU
+def test_handle_opened_from_image(pkg):
+    """What ranks != 0 do in the sharded run: open a device-resident copy of the serialized image
+    (genie_index_open) and search with it -- same rows as the handle that built the index."""
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    src = pkg.GenieIndex.build(d["ref_codes"], 15)
+    src.train_rmi([1000])
+    image = src.serialize()
+    a = src.to("cuda")
+    b = pkg.GenieIndex.from_image(image.clone().cuda())
+    assert b.info()["has_host"] == 0 and b.info()["n"] == a.info()["n"]
+    rd = B.reads_from_ref(d["ref_codes"], 3001, 150, 31)
+    for algo in ("bwa", "lut", "rmi"):
+        x, y = a.find_smems(algo, rd), b.find_smems(algo, rd)
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+    pats = rd[:500, :40]
+    assert torch.equal(a.sa_interval(pats), b.sa_interval(pats))
+    assert torch.equal(a.seed_lookup("rmi", rd[:500, :15]), b.seed_lookup("rmi", rd[:500, :15]))
+    pa, pb = a.locate(x[1][:1000]), b.locate(y[1][:1000])
+    assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+
+
+def test_rccl_broadcast_world1(pkg):
+    """parallel.broadcast_index over the nccl (= RCCL) backend, world size 1 on this GPU."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from genie_smem_amd import parallel, synth as B
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        d, _ = G.load("syn10k_K8")
+        ix = pkg.GenieIndex.build(d["ref_codes"], 8)
+        got = parallel.broadcast_index(ix, src=0, device="cuda:0")
+        assert got is ix and ix.blob is not None and ix.blob.is_cuda
+        buf = parallel.broadcast_image(ix.blob, src=0, device="cuda:0")
+        assert torch.equal(buf, ix.blob)
+        rd = B.reads_from_ref(d["ref_codes"], 64, 100, 5)
+        assert int(ix.find_smems("lut", rd)[2].abs().sum()) == 0
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------ rows -> coordinates (SURVEY 8f N3)
 def test_locate_positions(pkg):
     """genie_locate == ExactMatch.get_positions (suffix-array entries of rows lo..hi, 1-based, row order)
