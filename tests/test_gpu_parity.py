@@ -306,6 +306,34 @@ def test_fixed_length_slot_layouts(pkg, oracle_mod, algo):
             assert st[r] == 0 and rows[r].tolist() == out[i, :counts[i]].tolist(), (L, int(r))
 
 
+def test_stride_wider_than_fixed_length(pkg):
+    """C ABI: fixed_len < stride with no lens array -- the columns past fixed_len are never read."""
+    import ctypes as C
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ix = _index(pkg, "syn100k_K15")
+    N, L, stride = 1001, 150, 176
+    rd = B.reads_from_ref(d["ref_codes"], N, L, 321)
+    wide = np.full((N, stride), 9, np.uint8)                   # 9 would flag the read if it were looked at
+    wide[:, :L] = rd
+    want = ix.find_smems("lut", rd)
+    lib = pkg._native.lib()
+    dev = torch.as_tensor(wide).cuda()
+    status = torch.empty(N, dtype=torch.int32, device="cuda")
+    offsets = torch.empty(N + 1, dtype=torch.int64, device="cuda")
+    rows = torch.empty((int(want[0][-1]) + 8, 4), dtype=torch.int32, device="cuda")
+    wsb = int(lib.genie_find_smems_workspace_bytes(N, L))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())                                       # noqa: E731
+    pkg._native.check(lib.genie_find_smems_csr(ix._h, pkg._native.MODES["lut"], P(dev), None, N, stride, L, 1, P(offsets),
+                                               P(rows), rows.shape[0], P(status), P(ws), wsb,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "genie_find_smems_csr")
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0 and torch.equal(offsets, want[0])
+    assert torch.equal(rows[:int(offsets[-1])], want[1][:int(offsets[-1])])
+
+
 def test_lut_probe_option_changes_nothing(pkg):
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
