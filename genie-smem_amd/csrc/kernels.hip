@@ -28,7 +28,6 @@ constexpr int kWave = 64;
 
 // ------------------------------------------------------------------ small wave helpers
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // LDS traffic between lanes of ONE wave: the LDS executes a wave's instructions in order, so
 // only the compiler has to be stopped from reordering.

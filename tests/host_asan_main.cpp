@@ -1,0 +1,30 @@
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "genie_internal.h"
+using namespace genie;
+int main() {
+    for (int64_t n : {1, 5, 17, 1000, 70000}) {
+        std::vector<uint8_t> codes((size_t)n);
+        unsigned s = 12345u + (unsigned)n;
+        for (auto &c : codes) { s = s * 1664525u + 1013904223u; c = (s >> 24) & 3; }
+        if (n == 1000) for (size_t i = 0; i < 400; i++) codes[i] = i % 6 < 2 ? 3 : (i % 6 < 3 ? 0 : 1);   // repeats
+        for (int K : {0, 3, 8, 15}) {
+            HostIndex *h = nullptr;
+            int rc = build_host_index(codes.data(), n, nullptr, K, 7, &h);
+            if (rc) { printf("n=%lld K=%d rc=%d\n", (long long)n, K, rc); continue; }
+            if (K > 0 && n >= K) {
+                int32_t ex[2] = {10, 100};
+                double mean; int32_t worst;
+                rc = train_rmi(*h, 2, ex, &mean, &worst);
+                printf("n=%lld K=%d train rc=%d mean=%.2f worst=%d\n", (long long)n, K, rc, mean, worst);
+            }
+            BlobHeader hdr; fill_header(*h, &hdr);
+            std::vector<uint8_t> blob((size_t)hdr.total_bytes);
+            rc = serialize(*h, blob.data(), (int64_t)blob.size());
+            printf("n=%lld K=%d serialize rc=%d bytes=%lld P2=%d\n", (long long)n, K, rc, (long long)hdr.total_bytes, hdr.P2);
+            delete h;
+        }
+    }
+    return 0;
+}
