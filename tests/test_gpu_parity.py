@@ -334,6 +334,40 @@ def test_stride_wider_than_fixed_length(pkg):
     assert torch.equal(rows[:int(offsets[-1])], want[1][:int(offsets[-1])])
 
 
+@pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
+def test_long_exact_matches_and_low_complexity(pkg, oracle_mod, ds):
+    """Reads that ARE reference substrings (matches far longer than the 32-base inline keys, so the
+    comparison continues in the packed reference), the same with one substitution, reads running off the
+    reference end, and low-complexity reads -- against the CPU oracle, all three modes."""
+    d, _ = G.load(ds)
+    ref = d["ref_codes"]
+    n = len(ref)
+    rng = np.random.default_rng(17)
+    o = oracle_mod.Oracle(ref, 15)
+    o.set_rmi([], [np.asarray([o.n / 4.0 ** o.K])], [np.asarray([0.0])])
+    for L in (150, 255, 600):
+        starts = np.concatenate([rng.integers(0, n - L, 120), [0, n - L, n - L - 1], rng.integers(0, 6000, 40)])
+        rd = np.stack([ref[s0:s0 + L] for s0 in starts]).astype(np.uint8)
+        mut = rd[:60].copy()
+        pos = rng.integers(0, L, 60)
+        mut[np.arange(60), pos] = (mut[np.arange(60), pos] + 1 + rng.integers(0, 3, 60)) % 4
+        tail = np.stack([np.concatenate([ref[n - t:], rng.integers(0, 4, L - t).astype(np.uint8)]) for t in (1, 5, 6, 7, 8, 40)])
+        low = np.stack([np.full(L, b, np.uint8) for b in range(4)] +
+                       [np.tile(np.asarray(p_, np.uint8), L // len(p_) + 1)[:L] for p_ in ([0, 1], [3, 0, 0, 1, 1, 1], [2, 3, 2])])
+        batch = np.ascontiguousarray(np.concatenate([rd, mut, tail, low]))
+        for algo in ("bwa", "lut", "rmi"):
+            ix = _index_for(pkg, ds, algo)
+            offsets, smems, st = ix.find_smems(algo, batch)
+            rows = _rows_per_read(offsets, smems)
+            counts, out = o.find_smems_batch(algo, batch, nthreads=8)
+            st = st.cpu().numpy()
+            for r in range(len(batch)):
+                if counts[r] < 0:                       # e.g. a base that never occurs: flagged on both sides
+                    assert st[r] != 0, (L, algo, r)
+                else:
+                    assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (L, algo, r)
+
+
 def test_lut_probe_option_changes_nothing(pkg):
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
