@@ -721,12 +721,16 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     int32_t *st = d_status ? d_status : ws.status;
     int32_t *cnt = d_counts ? d_counts : ws.counts;
     constexpr bool CANPAIR = !WIDE;
-    auto ka = (CANPAIR && g.pair) ? match_stats_kernel<MODE, NS, WIDE, CANPAIR> : match_stats_kernel<MODE, NS, WIDE, false>;
+    // the K-mer hash probe (GENIE_OPT_LUT_PROBE) is compiled in only where it is asked for
+    constexpr bool CANPROBE = MODE == GENIE_MODE_LUT;
+    const bool probe = CANPROBE && ix->opt_lut_probe;
+    auto ka = (CANPAIR && g.pair) ? (probe ? match_stats_kernel<MODE, NS, WIDE, CANPAIR, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, CANPAIR, false>)
+                                  : (probe ? match_stats_kernel<MODE, NS, WIDE, false, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, false, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
                        fixed_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st, g.leaf_in_lds,
-                       ix->opt_lut_probe, g.blocks_a);
+                       g.blocks_a);
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     auto kb = traverse_kernel<MODE, WIDE>;
