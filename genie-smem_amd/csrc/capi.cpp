@@ -314,6 +314,7 @@ int genie_index_set_option(genie_index *ix, int32_t option, int32_t value)
     if (!ix) return GENIE_E_INVALID;
     switch (option) {
     case GENIE_OPT_LUT_PROBE: ix->opt_lut_probe = value != 0; return GENIE_OK;
+    case GENIE_OPT_SEARCH_ALL: ix->opt_search_all = value != 0; return GENIE_OK;
     default: return GENIE_E_INVALID;
     }
 }

@@ -14,7 +14,7 @@ struct uint2 { unsigned int x, y; };
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 5;
+constexpr uint32_t kBlobVersion = 6;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -29,6 +29,7 @@ struct HeadRec {
 };
 static_assert(sizeof(HeadRec) == 16, "HeadRec layout");
 constexpr uint32_t kHeadShort = 0x80000000u;
+constexpr int32_t kFlagDir16 = 1;
 
 // One slot of the device K-mer hash table (the GPU form of the reference's `lut` dict,
 // SMEM/LUT.py:33-35): key -> inclusive SA interval.  Empty slot: lo < 0.
@@ -92,7 +93,7 @@ struct BlobHeader {
     int64_t off_dir2;     // HeadRec [4^P2]: rows of every P2-mer + the inline key of the first of them
     int64_t dir2_entries;
     int32_t P2;           // 0 = no second-level table
-    int32_t pad2;
+    int32_t flags;        // kFlagDir16: every directory entry is within 65535 rows of entry (x & ~15)
     int64_t off_rmi_err;  // int32 [rmi_err_entries]: per leaf model, max |int(prediction) - row| over the training keys
     int64_t rmi_err_entries;   // 0 = no error table (model installed from coefficients)
 };
@@ -108,6 +109,7 @@ struct DevIndex {
     const RmiModel *rmi;
     const HeadRec *dir2;   // second-level range table (global, L2-resident), or null
     const int32_t *rmi_err; // per-leaf error bounds of a natively trained RMI, or null
+    int32_t flags;
     int32_t n;
     int32_t K;
     int32_t P;
@@ -136,6 +138,7 @@ struct HostIndex {
     std::vector<uint32_t> dir;
     int32_t P2 = 0;
     std::vector<HeadRec> dir2;           // 4^P2 entries
+    int32_t flags = 0;
     std::vector<uint32_t> lut_code;      // sorted distinct K-mers
     std::vector<int32_t> lut_lo, lut_hi;
     std::vector<LutSlot> lut_slots;
@@ -167,6 +170,7 @@ struct genie_index {
     int64_t blob_bytes = 0;
     int32_t num_cus = 0;
     int32_t opt_lut_probe = 0;       // GENIE_OPT_LUT_PROBE
+    int32_t opt_search_all = 0;      // GENIE_OPT_SEARCH_ALL
     void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel
     void *ev_search_end = nullptr;
 };

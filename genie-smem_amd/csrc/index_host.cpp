@@ -159,6 +159,12 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
         h->dir.resize((size_t)nb + 1);
         uint32_t acc = 0;
         for (int64_t x = 0; x <= nb; x++) { acc += d[(size_t)x]; h->dir[(size_t)x] = acc; }
+        // can the LDS copy be 16-bit deltas against every 16th entry? (the sampled search stages it so)
+        {
+            bool ok = true;
+            for (int64_t x = 0; x <= nb && ok; x++) ok = h->dir[(size_t)x] - h->dir[(size_t)(x & ~(int64_t)15)] <= 65535u;
+            h->flags = ok ? kFlagDir16 : 0;
+        }
         // padded codes of the tail suffixes (row 0 = '$' has length 0 and pads to 0)
         for (int l = 0; l < 8; l++) {
             if (l < P && l <= n) h->padtail[l] = code_at(codes, n - l, l) << (2 * (P - l));
@@ -245,6 +251,7 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->lut_keys = (int64_t)h.lut_code.size();
     hdr->rmi_models = (int64_t)h.rmi.size();
     hdr->P2 = h.P2;
+    hdr->flags = h.flags;
     hdr->dir2_entries = (int64_t)h.dir2.size();
     hdr->nlev = h.nlev;
     for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
@@ -443,6 +450,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->rmi = (const RmiModel *)(p + hdr.off_rmi);
     out->dir2 = hdr.P2 > 0 ? (const HeadRec *)(p + hdr.off_dir2) : nullptr;
     out->P2 = hdr.P2;
+    out->flags = hdr.flags;
     out->rmi_err = hdr.rmi_err_entries > 0 ? (const int32_t *)(p + hdr.off_rmi_err) : nullptr;
     out->n = (int32_t)hdr.n;
     out->K = hdr.K;

@@ -89,8 +89,17 @@ struct QRecs {
 // suffix has fewer than P bases ("tails", P-1 of them plus the '$' row) need the two
 // corrections below; padtail[l] is the A-padded code of the tail of length l.
 //
+// The directory as 16-bit deltas against every 16th entry (36 KB instead of 64 KB of LDS):
+// dir[x] = coarse[x >> 4] + delta[x].  Usable when the image carries kFlagDir16.
+struct Dir16 {
+    const uint32_t *coarse;
+    const uint16_t *delta;
+    __device__ __forceinline__ uint32_t operator[](uint32_t x) const { return coarse[x >> 4] + delta[x]; }
+};
+
 // Rows with prefix `code` (m bases, 1 <= m <= P) are exactly [dir_lb, dir_ub).
-__device__ __forceinline__ uint32_t dir_lb(const DevIndex &ix, const uint32_t *dir, uint32_t code, int m)
+template <class D>
+__device__ __forceinline__ uint32_t dir_lb(const DevIndex &ix, const D dir, uint32_t code, int m)
 {
     const uint32_t x = code << (2 * (ix.P - m));
     uint32_t v = dir[x];
@@ -101,7 +110,8 @@ __device__ __forceinline__ uint32_t dir_lb(const DevIndex &ix, const uint32_t *d
     return v;
 }
 
-__device__ __forceinline__ uint32_t dir_ub(const DevIndex &ix, const uint32_t *dir, uint32_t code, int m)
+template <class D>
+__device__ __forceinline__ uint32_t dir_ub(const DevIndex &ix, const D dir, uint32_t code, int m)
 {
     const uint32_t x = (code + 1) << (2 * (ix.P - m));
     uint32_t v = dir[x];
@@ -582,6 +592,7 @@ std::string g_err;
 struct Geometry {
     int grid, block, lds, leaf_in_lds;
     int blocks_a;    // paired search: blocks [0, blocks_a) take role A, the rest role B
+    int sampled;     // sampled search (match_stats_sampled_kernel) with this work-list capacity, 0 = not used
     int pair;        // narrow fixed-length batch whose last slot holds <= 32 positions: two reads per wave iteration
     int ns;          // position slots per chunk in K_A (1..4)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
@@ -658,6 +669,34 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
         a = a < 1 ? 1 : (a > grid - 1 ? grid - 1 : a);
         g->blocks_a = (int)a;
     }
+    g->sampled = 0;
+    if (!g->wide && (d.flags & kFlagDir16) && max_len > 0 && !ix->opt_search_all) {
+        // sampled search: directory as 16-bit deltas, four reads per wave with their fwd rows and a work list
+        const int ncoarse = ((d.dir_entries - 1) >> 4) + 1;
+        const int dir16 = ((ncoarse * 4 + 15) & ~15) + ((d.dir_entries * 2 + 15) & ~15);
+        const int wl_cap = 5 * max_len;
+        const int pw = 5 * g->qp_words * 8 + 8 * 8 + 32 + ((5 * g->fwd_stride + 15) & ~15) + ((wl_cap * 2 + 15) & ~15);
+        int leaf2 = 0;
+        if (mode == GENIE_MODE_RMI) {
+            const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
+            int room = lds_cap / 2 - dir16 - 16 * pw;
+            if (room < 0) room = 0;
+            leaf2 = std::min(cnt, room / 16) * 16;
+        }
+        const int lds2 = dir16 + leaf2 + 16 * pw;
+        if (lds2 <= lds_cap / 2) {
+            g->sampled = wl_cap;
+            g->lds = lds2;
+            g->leaf_in_lds = leaf2 / 16;
+            g->block = 16 * kWave;
+            long long gr = (long long)cus * 2;
+            const long long need2 = (N + 16 * 5 - 1) / (16 * 5);
+            if (gr > need2) gr = need2;
+            if (gr < 1) gr = 1;
+            g->grid = (int)gr;
+            return GENIE_OK;
+        }
+    }
     g->grid = (int)grid;
     g->block = waves * kWave;
     g->lds = lds;
@@ -728,6 +767,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                                   : (probe ? match_stats_kernel<MODE, NS, WIDE, false, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, false, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
+    if (!WIDE && g.sampled) {
+        auto ks = probe ? match_stats_sampled_kernel<MODE, CANPROBE> : match_stats_sampled_kernel<MODE, false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL(ks, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
+                           reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
+                           g.leaf_in_lds, g.sampled, [] { const char *e = std::getenv("GENIE_SAMPLE_SHIFT"); const int v = e ? std::atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }());
+    } else
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
                        fixed_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st, g.leaf_in_lds,
                        g.blocks_a);

@@ -24,7 +24,7 @@ for name, f in (("FETCH_SIZE", "pmc_fetch_counter_collection.csv"), ("WRITE_SIZE
         if row["Counter_Name"] == name:
             agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     for k, v in agg.items():
-        m = re.search(r"(match_stats_kernel<[^>]*>|traverse_kernel<[^>]*>|interval_kernel<[^>]*>|interval_kernel|compact_\w+|sa_interval_kernel|seed_lookup_kernel<\d>)", k)
+        m = re.search(r"(match_stats\w*kernel<[^>]*>|traverse_kernel<[^>]*>|interval_kernel<[^>]*>|interval_kernel|compact_\w+|sa_interval_kernel|seed_lookup_kernel<\d>)", k)
         if m:
             pmc.setdefault(m.group(1), {})[name + "_KiB_per_launch"] = sum(v) / len(v)
             pmc[m.group(1)]["launches"] = len(v)
@@ -40,7 +40,7 @@ json.dump(out, open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
 # the value bench.py reports as roofline.traffic (dominant kernel, corrected bytes per launch)
 tpath = os.path.join(here, "pmc_traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-dom = [k for k in pmc if k.startswith("match_stats_kernel")]
+dom = [k for k in pmc if k.startswith("match_stats")]
 if dom:
     traffic[key] = pmc[dom[0]]["hbm_bytes_per_launch_gfx950_corrected"]
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)

@@ -277,17 +277,27 @@ def test_vs_oracle_fresh_reads(pkg, oracle_mod, ds, L, kind, algo):
         assert rows[r].tolist() == out[r, :counts[r]].tolist(), r
 
 
+@pytest.mark.parametrize("search_all", [0, 1])
 @pytest.mark.parametrize("algo", ["bwa", "lut", "rmi"])
-def test_fixed_length_slot_layouts(pkg, oracle_mod, algo):
+def test_fixed_length_slot_layouts(pkg, oracle_mod, algo, search_all):
     """Fixed-length batches whose last 64-position slot holds at most 32 positions are searched two reads
     per wave with a shared slot; lengths on both sides of every boundary, an odd batch (last read has
     no partner), and flagged reads inside pairs."""
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
     ix = _index_for(pkg, "syn100k_K15", algo)
+    ix.set_option(pkg._native.OPT_SEARCH_ALL, search_all)
     o = oracle_mod.Oracle(d["ref_codes"], 15)
     if algo == "rmi":
         o.set_rmi([], [np.asarray([o.n / 4.0 ** o.K])], [np.asarray([0.0])])
+    try:
+        _slot_layout_cases(pkg, ix, o, d, algo)
+    finally:
+        ix.set_option(pkg._native.OPT_SEARCH_ALL, 0)
+
+
+def _slot_layout_cases(pkg, ix, o, d, algo):
+    from genie_smem_amd import synth as B
     for L in (15, 20, 31, 32, 33, 64, 65, 70, 96, 97, 128, 129, 131, 134, 150, 160, 161, 192, 193, 200, 224, 225, 255):
         n_reads = 301
         rd = B.reads_from_ref(d["ref_codes"], n_reads, L, 1000 + L)
@@ -366,6 +376,44 @@ def test_long_exact_matches_and_low_complexity(pkg, oracle_mod, ds):
                     assert st[r] != 0, (L, algo, r)
                 else:
                     assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (L, algo, r)
+
+
+@pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
+def test_sampled_search_equals_full_search(pkg, oracle_mod, ds):
+    """Default search (every 4th position, then only the gaps whose ends disagree) against
+    GENIE_OPT_SEARCH_ALL on from-ref, random, exact and ragged batches, all modes; one batch also
+    against the CPU oracle so that both are pinned."""
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load(ds)
+    ref = d["ref_codes"]
+    n = len(ref)
+    rng = np.random.default_rng(23)
+    batches = []
+    for L in (15, 33, 64, 100, 150, 187):
+        rd = B.reads_from_ref(ref, 403, L, 500 + L)
+        rd[5, L // 3] = 7                                            # one flagged read per batch
+        batches.append((rd, None))
+    batches.append((B.reads_random(1001, 150, 9), None))
+    batches.append((np.stack([ref[s0:s0 + 150] for s0 in rng.integers(0, n - 150, 600)]).astype(np.uint8), None))
+    rag = B.reads_from_ref(ref, 300, 180, 77)
+    batches.append((rag, rng.integers(0, 181, 300).astype(np.int32)))
+    for algo in ("bwa", "lut", "rmi"):
+        ix = _index_for(pkg, ds, algo)
+        for rd, lens in batches:
+            a = ix.find_smems(algo, rd, lens=lens)
+            ix.set_option(pkg._native.OPT_SEARCH_ALL, 1)
+            try:
+                b = ix.find_smems(algo, rd, lens=lens)
+            finally:
+                ix.set_option(pkg._native.OPT_SEARCH_ALL, 0)
+            assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (algo, rd.shape)
+    o = oracle_mod.Oracle(ref, 15)
+    rd = batches[7][0][:200]
+    counts, out = o.find_smems_batch("lut", rd, nthreads=8)
+    rows = _rows_per_read(*_index_for(pkg, ds, "lut").find_smems("lut", rd)[:2])
+    for r in range(len(rd)):
+        assert rows[r].tolist() == out[r, :counts[r]].tolist()
 
 
 def test_lut_probe_option_changes_nothing(pkg):

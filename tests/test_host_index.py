@@ -127,6 +127,7 @@ def _parse(img):
     h = dict(zip(keys, f[:18]))
     h["padtail"] = list(f[-14:-6])
     h["off_dir2"], h["dir2_entries"], h["P2"] = f[-6], f[-5], f[-4]
+    h["flags"] = f[-3]
     h["off_rmi_err"], h["rmi_err_entries"] = f[-2], f[-1]
     return h
 
