@@ -593,6 +593,7 @@ struct Geometry {
     int grid, block, lds, leaf_in_lds;
     int blocks_a;    // paired search: blocks [0, blocks_a) take role A, the rest role B
     int sampled;     // sampled search (match_stats_sampled_kernel) with this work-list capacity, 0 = not used
+    int grp, sshift; // its reads per wave iteration and log2 of the sampling stride
     int pair;        // narrow fixed-length batch whose last slot holds <= 32 positions: two reads per wave iteration
     int ns;          // position slots per chunk in K_A (1..4)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
@@ -623,6 +624,13 @@ inline void shape_for(int max_len, Geometry *g)
     g->hm_words = (g->wide ? (max_len + 63) / 64 : g->ns) + 1;
     g->fwd_stride = fwd_row_bytes(max_len, g->wide);
     g->kj_row = (std::max(max_len, 1) + 7) & ~7;
+}
+
+inline int sample_shift()
+{
+    const char *e = std::getenv("GENIE_SAMPLE_SHIFT");
+    const int v = e ? std::atoi(e) : 2;
+    return v >= 1 && v <= 4 ? v : 2;
 }
 
 int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len, long long N, Geometry *g)
@@ -671,11 +679,21 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
     }
     g->sampled = 0;
     if (!g->wide && (d.flags & kFlagDir16) && max_len > 0 && !ix->opt_search_all) {
-        // sampled search: directory as 16-bit deltas, four reads per wave with their fwd rows and a work list
+        // sampled search: directory as 16-bit deltas; `grp` reads per wave with their fwd rows and a work
+        // list: as many as keep two blocks per CU in LDS and fill, not overflow, one 192-entry chunk of
+        // first-round searches
+        const int sshift = sample_shift();
         const int ncoarse = ((d.dir_entries - 1) >> 4) + 1;
         const int dir16 = ((ncoarse * 4 + 15) & ~15) + ((d.dir_entries * 2 + 15) & ~15);
-        const int wl_cap = 5 * max_len;
-        const int pw = 5 * g->qp_words * 8 + 8 * 8 + 32 + ((5 * g->fwd_stride + 15) & ~15) + ((wl_cap * 2 + 15) & ~15);
+        const int ns0 = ((max_len - 1) >> sshift) + 1;
+        int grp = std::min(8, std::max(1, 192 / ns0));
+        int wl_cap = 0, pw = 0;
+        for (; grp >= 1; grp--) {
+            wl_cap = grp * max_len;
+            pw = grp * g->qp_words * 8 + 8 * 8 + 32 + ((grp * g->fwd_stride + 15) & ~15) + ((wl_cap * 2 + 15) & ~15);
+            if (dir16 + 16 * pw <= lds_cap / 2) break;
+        }
+        if (grp < 1) grp = 1;
         int leaf2 = 0;
         if (mode == GENIE_MODE_RMI) {
             const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
@@ -686,11 +704,13 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
         const int lds2 = dir16 + leaf2 + 16 * pw;
         if (lds2 <= lds_cap / 2) {
             g->sampled = wl_cap;
+            g->grp = grp;
+            g->sshift = sshift;
             g->lds = lds2;
             g->leaf_in_lds = leaf2 / 16;
             g->block = 16 * kWave;
             long long gr = (long long)cus * 2;
-            const long long need2 = (N + 16 * 5 - 1) / (16 * 5);
+            const long long need2 = (N + 16 * grp - 1) / (16 * grp);
             if (gr > need2) gr = need2;
             if (gr < 1) gr = 1;
             g->grid = (int)gr;
@@ -768,11 +788,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     if (!WIDE && g.sampled) {
-        auto ks = probe ? match_stats_sampled_kernel<MODE, CANPROBE> : match_stats_sampled_kernel<MODE, false>;
+        // five reads per wave is what 150-base reads get: that instantiation has the group size folded in
+        auto ks = g.grp == 5 ? (probe ? match_stats_sampled_kernel<MODE, CANPROBE, 5> : match_stats_sampled_kernel<MODE, false, 5>)
+                             : (probe ? match_stats_sampled_kernel<MODE, CANPROBE, 0> : match_stats_sampled_kernel<MODE, false, 0>);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(ks, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
                            reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
-                           g.leaf_in_lds, g.sampled, [] { const char *e = std::getenv("GENIE_SAMPLE_SHIFT"); const int v = e ? std::atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }());
+                           g.leaf_in_lds, g.sampled, g.sshift, g.grp);
     } else
     hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
                        fixed_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st, g.leaf_in_lds,
