@@ -416,6 +416,53 @@ def test_sampled_search_equals_full_search(pkg, oracle_mod, ds):
         assert rows[r].tolist() == out[r, :counts[r]].tolist()
 
 
+def test_randomized_configurations(pkg, oracle_mod):
+    """Seeded sweep over reference size and content (tiny, repeat-rich, a base missing), K, read length
+    and read kind; BWA, LUT and natively trained RMI against the CPU oracle, default (sampled) search."""
+    rng = np.random.default_rng(20260)
+    cases = 0
+    for n in (5, 37, 400, 3000, 70000):
+        for rep in range(4 if n < 70000 else 2):
+            alphabet = 4 if rng.random() < 0.7 else 3                     # sometimes T never occurs
+            ref = rng.integers(0, alphabet, n).astype(np.uint8)
+            if n >= 400 and rep % 2:                                        # splice in a tandem repeat
+                unit = rng.integers(0, alphabet, int(rng.integers(1, 7))).astype(np.uint8)
+                span = int(min(n // 2, 600))
+                ref[:span] = np.tile(unit, span // len(unit) + 1)[:span]
+            K = int(rng.choice([k for k in (3, 6, 8, 12, 15) if k <= n]))
+            L = int(rng.integers(max(K, 1), 256))
+            N = 61
+            reads = np.empty((N, L), np.uint8)
+            for r in range(N):
+                kind = r % 3
+                if kind == 0 or n < 3:
+                    reads[r] = rng.integers(0, alphabet, L)
+                else:
+                    buf = []
+                    while sum(len(b) for b in buf) < L:
+                        p0 = int(rng.integers(0, n))
+                        s0 = int(rng.integers(1, 31 if kind == 1 else 4 * L))
+                        buf.append(ref[p0:p0 + s0])
+                    reads[r] = np.concatenate(buf)[:L]
+            ix = pkg.GenieIndex.build(ref, K)
+            coefs, icpts, _, _, _ = ix.train_rmi([10])
+            ix = ix.to("cuda")
+            o = oracle_mod.Oracle(ref, K)
+            o.set_rmi([10], coefs, icpts)
+            for algo in ("bwa", "lut", "rmi"):
+                offsets, smems, st = ix.find_smems(algo, reads)
+                rows = _rows_per_read(offsets, smems)
+                counts, out = o.find_smems_batch(algo, reads, nthreads=8)
+                st = st.cpu().numpy()
+                for r in range(N):
+                    if counts[r] < 0:
+                        assert st[r] != 0, (n, K, L, algo, r)
+                    else:
+                        assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (n, K, L, algo, r)
+                cases += 1
+    assert cases == 54
+
+
 def test_lut_probe_option_changes_nothing(pkg):
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
