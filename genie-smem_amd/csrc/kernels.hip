@@ -687,6 +687,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
         const int dir16 = ((ncoarse * 4 + 15) & ~15) + ((d.dir_entries * 2 + 15) & ~15);
         const int ns0 = ((max_len - 1) >> sshift) + 1;
         int grp = std::min(8, std::max(1, 192 / ns0));
+        if (const char *e = std::getenv("GENIE_SAMPLE_GROUP")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) grp = v; }   // tuning
         int wl_cap = 0, pw = 0;
         for (; grp >= 1; grp--) {
             wl_cap = grp * max_len;
