@@ -594,6 +594,7 @@ struct Geometry {
     int blocks_a;    // paired search: blocks [0, blocks_a) take role A, the rest role B
     int sampled;     // sampled search (match_stats_sampled_kernel) with this work-list capacity, 0 = not used
     int grp, sshift; // its reads per wave iteration and log2 of the sampling stride
+    int win;         // long reads: window of the sampled search (match_stats_sampled_long_kernel), 0 = not used
     int pair;        // narrow fixed-length batch whose last slot holds <= 32 positions: two reads per wave iteration
     int ns;          // position slots per chunk in K_A (1..4)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
@@ -678,6 +679,37 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
         g->blocks_a = (int)a;
     }
     g->sampled = 0;
+    g->win = 0;
+    if (g->wide && (d.flags & kFlagDir16) && !ix->opt_search_all) {
+        // sampled search for long reads: one wave per read, windows of 704 positions
+        const int win = 704;
+        const int ncoarse = ((d.dir_entries - 1) >> 4) + 1;
+        const int dir16 = ((ncoarse * 4 + 15) & ~15) + ((d.dir_entries * 2 + 15) & ~15);
+        const int pw = g->qp_words * 8 + (((win + 8) * 2 + 15) & ~15) + ((win * 2 + 15) & ~15);
+        int w = (lds_cap / 2 - dir16) / pw;
+        int w2 = 1;
+        while (w2 * 2 <= w && w2 < 16) w2 *= 2;
+        if (w >= 4) {
+            int leaf2 = 0;
+            if (mode == GENIE_MODE_RMI) {
+                const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
+                int room = lds_cap / 2 - dir16 - w2 * pw;
+                if (room < 0) room = 0;
+                leaf2 = std::min(cnt, room / 16) * 16;
+            }
+            g->win = win;
+            g->sshift = sample_shift();
+            g->lds = dir16 + leaf2 + w2 * pw;
+            g->leaf_in_lds = leaf2 / 16;
+            g->block = w2 * kWave;
+            long long gr = (long long)cus * 2;
+            const long long need2 = (N + w2 - 1) / w2;
+            if (gr > need2) gr = need2;
+            if (gr < 1) gr = 1;
+            g->grid = (int)gr;
+            return GENIE_OK;
+        }
+    }
     if (!g->wide && (d.flags & kFlagDir16) && max_len > 0 && !ix->opt_search_all) {
         // sampled search: directory as 16-bit deltas; `grp` reads per wave with their fwd rows and a work
         // list: as many as keep two blocks per CU in LDS and fill, not overflow, one 192-entry chunk of
@@ -788,7 +820,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                                   : (probe ? match_stats_kernel<MODE, NS, WIDE, false, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, false, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
-    if (!WIDE && g.sampled) {
+    if (WIDE && g.win) {
+        auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL(kl, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
+                           reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
+                           g.leaf_in_lds, g.sshift, g.win);
+    } else if (!WIDE && g.sampled) {
         // five reads per wave is what 150-base reads get: that instantiation has the group size folded in
         auto ks = g.grp == 5 ? (probe ? match_stats_sampled_kernel<MODE, CANPROBE, 5> : match_stats_sampled_kernel<MODE, false, 5>)
                              : (probe ? match_stats_sampled_kernel<MODE, CANPROBE, 0> : match_stats_sampled_kernel<MODE, false, 0>);

@@ -216,9 +216,9 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  * so the extra probe only costs time (measured: DESIGN.md) and is off by default. */
 enum { GENIE_OPT_LUT_PROBE = 1, GENIE_OPT_SEARCH_ALL = 2 };
 /* GENIE_OPT_SEARCH_ALL (default 0): the matching statistics fwd[] are non-decreasing along a read, so by
- * default reads of up to 255 bases are searched at every 4th position first and only the gaps whose two
- * ends disagree are searched inside (identical results; 1.6x faster on reads that match the reference
- * end to end, ~10 % slower on uniformly random reads).  Value 1 searches every position. */
+ * default reads are searched at every 4th position first and only the gaps whose two ends disagree are
+ * searched inside (identical results; 1.6x to 3.7x faster on reads that match the reference end to end,
+ * ~10 % slower on uniformly random reads).  Value 1 searches every position. */
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
 
 /* Profiling hook: two hipEvent_t (as void*, created by the caller with timing enabled) that the next

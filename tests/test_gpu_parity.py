@@ -398,6 +398,13 @@ def test_sampled_search_equals_full_search(pkg, oracle_mod, ds):
     batches.append((np.stack([ref[s0:s0 + 150] for s0 in rng.integers(0, n - 150, 600)]).astype(np.uint8), None))
     rag = B.reads_from_ref(ref, 300, 180, 77)
     batches.append((rag, rng.integers(0, 181, 300).astype(np.int32)))
+    for L in (256, 705, 1409, 3000):                                  # long reads: windows of 704 positions
+        lr = B.reads_from_ref(ref, 41, L, 900 + L)
+        lr[3, L - 2] = 6
+        batches.append((lr, None))
+    batches.append((np.stack([ref[s0:s0 + 2500] for s0 in rng.integers(0, n - 2500, 30)]).astype(np.uint8), None))
+    lrag = B.reads_from_ref(ref, 60, 1500, 78)
+    batches.append((lrag, rng.integers(0, 1501, 60).astype(np.int32)))
     for algo in ("bwa", "lut", "rmi"):
         ix = _index_for(pkg, ds, algo)
         for rd, lens in batches:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Search-kernel variants on two read distributions: ms per 10^6 x 150 bp batch (whole CSR call)."""
+"""Search-kernel variants on two read distributions: ms per batch (whole CSR call; KC_L, KC_N select read length and count)."""
 import ctypes as C, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,8 @@ import genie_smem_amd as g
 from genie_smem_amd import synth
 
 def main():
-    n, L, N, K = 100_000, 150, 1_000_000, 15
+    n, K = 100_000, 15
+    L, N = int(os.environ.get("KC_L", "150")), int(os.environ.get("KC_N", "1000000"))
     ref = synth.synth_ref(n, n)
     ix = g.GenieIndex.build(ref, K)
     ix.train_rmi([1000])
@@ -17,7 +18,7 @@ def main():
             "exact": np.stack([ref[s:s + L] for s in np.random.default_rng(3).integers(0, n - L, N)]).astype(np.uint8)}
     ws_b = int(lib.genie_find_smems_workspace_bytes(N, L))
     status = torch.empty(N, dtype=torch.int32, device="cuda"); offsets = torch.empty(N + 1, dtype=torch.int64, device="cuda")
-    out = torch.empty((N * 60, 4), dtype=torch.int32, device="cuda"); ws = torch.empty(ws_b, dtype=torch.uint8, device="cuda")
+    out = torch.empty((N * max(60, L // 2), 4), dtype=torch.int32, device="cuda"); ws = torch.empty(ws_b, dtype=torch.uint8, device="cuda")
     P = lambda t: C.c_void_p(t.data_ptr())
     s0 = torch.cuda.current_stream()
     for name, rd in sets.items():
