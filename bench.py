@@ -221,7 +221,7 @@ def main():
                        "smems_per_read": round(smems_per_read, 3), "launch": launch,
                        "index_build_plus_broadcast_s": round(t_build, 3)},
             "roofline": {"bound": "hbm", "kernel": (f"match_stats_sampled_kernel<{mode_id}, false, {5 if min(8, max(1, 192 // ((L - 1) // 4 + 1))) == 5 else 0}>" if L <= 255 else
-                                                   f"match_stats_kernel<{mode_id}, {ns}, {'true' if L > 255 else 'false'}, ...>"), "achieved": achieved,
+                                                   f"match_stats_sampled_long_kernel<{mode_id}, false>"), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_read": bytes_search, "kernel_ms_avg": kern_ms_avg,
                          "kernel_ms_min": float(np.min(kern_ms)),
