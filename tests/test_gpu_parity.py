@@ -470,6 +470,48 @@ def test_randomized_configurations(pkg, oracle_mod):
     assert cases == 54
 
 
+def test_sampled_search_fuzz_lengths(pkg):
+    """Differential sweep: sampled search against the search of every position over random read lengths
+    (1..3000, so both the short-read groups and the long-read windows with every alignment of their
+    boundaries), batch sizes and read kinds."""
+    import torch
+    d, _ = G.load("big100k_K15")
+    ref = d["ref_codes"]
+    n = len(ref)
+    rng = np.random.default_rng(4711)
+    ix = {a: _index_for(pkg, "big100k_K15", a) for a in ("bwa", "lut", "rmi")}
+    for it in range(48):
+        L = int(rng.choice([rng.integers(1, 256), rng.integers(256, 3001), 704 + rng.integers(-2, 3), 1408 + rng.integers(-2, 3)]))
+        N = int(rng.integers(1, 120))
+        rd = np.empty((N, L), np.uint8)
+        for r in range(N):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                rd[r] = rng.integers(0, 4, L)
+            elif kind == 1 and L <= n:
+                s0 = int(rng.integers(0, n - L + 1))
+                rd[r] = ref[s0:s0 + L]
+                if L > 3 and rng.random() < 0.5:
+                    rd[r, int(rng.integers(0, L))] ^= 1
+            else:
+                buf = []
+                while sum(len(b) for b in buf) < L:
+                    p0 = int(rng.integers(0, n))
+                    buf.append(ref[p0:p0 + int(rng.integers(1, 200))])
+                rd[r] = np.concatenate(buf)[:L]
+        algo = ("bwa", "lut", "rmi")[it % 3]
+        if algo != "bwa" and L < 15:
+            algo = "bwa"
+        h = ix[algo]
+        a = h.find_smems(algo, rd)
+        h.set_option(pkg._native.OPT_SEARCH_ALL, 1)
+        try:
+            b = h.find_smems(algo, rd)
+        finally:
+            h.set_option(pkg._native.OPT_SEARCH_ALL, 0)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (it, algo, L, N)
+
+
 def test_lut_probe_option_changes_nothing(pkg):
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
