@@ -46,6 +46,18 @@ K = 15
 EXPERTS = [1000]
 
 
+def search_kernel_name(mode_id, L, search_all):
+    """Instantiation of the dominant (search) kernel the library picks for fixed-length reads of L bases."""
+    ns = min(4, (L + 63) // 64)
+    if search_all:
+        pair = "true" if L <= 255 and L - 64 * (ns - 1) <= 32 else "false"
+        return f"match_stats_kernel<{mode_id}, {ns}, {'true' if L > 255 else 'false'}, {pair}, false>"
+    if L > 255:
+        return f"match_stats_sampled_long_kernel<{mode_id}, false>"
+    grp = min(8, max(1, 192 // ((L - 1) // 4 + 1)))
+    return f"match_stats_sampled_kernel<{mode_id}, false, {5 if grp == 5 else 0}>"
+
+
 def build_index(cfg, device):
     ref = synth.synth_ref(cfg["n"], cfg["ref_seed"])
     m = g.ExactMatch(f"REF_{cfg['n']}.fa", device=str(device))
@@ -86,6 +98,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=None, help="off-config read length (sweeps only; named in config.workload)")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--search-all", action="store_true", help="GENIE_OPT_SEARCH_ALL: search every read position (A/B runs)")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -116,6 +129,8 @@ def main():
     if world > 1:
         ix = parallel.broadcast_index(ix, src=0, device=device)
     t_build = time.perf_counter() - t_build
+    if args.search_all:
+        ix.set_option(g._native.OPT_SEARCH_ALL, 1)
 
     # ---- this rank's batch (weak scaling: same shape on every rank, seed + rank)
     ref_codes = synth.synth_ref(cfg["n"], cfg["ref_seed"])
@@ -214,14 +229,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32 (2-bit packed bases, int32 SA rows; f64 only in the RMI predict)",
             "data": "synthetic",
-            "config": {"workload": cfg["name"] if mode == cfg["mode"] else cfg["name"] + f" [mode={mode}]",
+            "config": {"workload": (cfg["name"] if mode == cfg["mode"] else cfg["name"] + f" [mode={mode}]") + (" [search-all]" if args.search_all else ""),
                        "reference_bases": cfg["n"], "reads_per_gpu_per_step": n_reads, "read_len": L, "K": K,
                        "mode": mode, "rmi_experts": EXPERTS, "read_distribution": "from-ref segments U{1..30}",
                        "parallelism": f"query-sharded x{world}, index replicated (one RCCL broadcast)",
                        "smems_per_read": round(smems_per_read, 3), "launch": launch,
                        "index_build_plus_broadcast_s": round(t_build, 3)},
-            "roofline": {"bound": "hbm", "kernel": (f"match_stats_sampled_kernel<{mode_id}, false, {5 if min(8, max(1, 192 // ((L - 1) // 4 + 1))) == 5 else 0}>" if L <= 255 else
-                                                   f"match_stats_sampled_long_kernel<{mode_id}, false>"), "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": search_kernel_name(mode_id, L, args.search_all), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_read": bytes_search, "kernel_ms_avg": kern_ms_avg,
                          "kernel_ms_min": float(np.min(kern_ms)),
