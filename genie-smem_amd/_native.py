@@ -22,11 +22,12 @@ MODE_BWA, MODE_LUT, MODE_RMI = 0, 1, 2
 MODES = {"bwa": MODE_BWA, "lut": MODE_LUT, "rmi": MODE_RMI}
 OPT_LUT_PROBE = 1
 OPT_SEARCH_ALL = 2
+OPT_LEGACY_SEARCH = 3
 READ_OK, READ_BAD_BASE, READ_TOO_SHORT, READ_ABSENT_BASE, READ_OVERFLOW = 0, 1, 2, 3, 4
 
 # every symbol include/genie_smem.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "genie_abi_version", "genie_index_create", "genie_index_create_from_sa", "genie_index_set_rmi",
+    "genie_abi_version", "genie_index_create", "genie_index_create_from_sa", "genie_index_create_ex", "genie_index_set_rmi",
     "genie_index_info", "genie_index_suffix_array", "genie_index_lut_arrays", "genie_index_blob_bytes",
     "genie_index_serialize", "genie_index_open", "genie_index_to_device", "genie_index_destroy",
     "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_csr", "genie_find_smems_workspace_bytes",
@@ -52,7 +53,7 @@ class GenieError(RuntimeError):
 
 def build(force=False):
     """Compile libgenie_smem.so for gfx950 with hipcc (csrc/Makefile), in-tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "short_read_kernel.inc", "capi.cpp", "index_host.cpp", "genie_internal.h", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "short_read_kernel.inc", "match_table_kernel.inc", "capi.cpp", "index_host.cpp", "genie_internal.h", "Makefile")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "genie_smem.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
@@ -80,6 +81,7 @@ def lib():
         "genie_abi_version": (C.c_int, []),
         "genie_index_create": (C.c_int, [u8p, i64, i32, i32, vpp]),
         "genie_index_create_from_sa": (C.c_int, [u8p, i64, i32p, i32, i32, vpp]),
+        "genie_index_create_ex": (C.c_int, [u8p, i64, i32p, i32, i32, i32, vpp]),
         "genie_index_set_rmi": (C.c_int, [vp, i32, i32p, i32p, dp, dp]),
         "genie_index_info": (C.c_int, [vp, C.POINTER(GenieInfo)]),
         "genie_index_suffix_array": (i32p, [vp]),

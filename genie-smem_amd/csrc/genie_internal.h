@@ -14,7 +14,7 @@ struct uint2 { unsigned int x, y; };
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 6;
+constexpr uint32_t kBlobVersion = 7;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -30,6 +30,26 @@ struct HeadRec {
 static_assert(sizeof(HeadRec) == 16, "HeadRec layout");
 constexpr uint32_t kHeadShort = 0x80000000u;
 constexpr int32_t kFlagDir16 = 1;
+
+// Match-table entry (one per P2-mer, 32 bytes = ONE aligned fetch): everything the match-statistics
+// kernel needs to know about the suffixes that start with this P2-mer, without their order or rows.
+//   meta byte 0  base   P2 when the P2-mer occurs, else the longest prefix of it (0 .. P2-1) that occurs
+//                       anywhere in the reference (also inside its last P2-1 bases)
+//   meta byte 1  lmask  0x1F when the P2-mer occurs and the entry is not slow, else 0:  match >= base + (lcp & lmask)
+//   meta byte 2  flags  kMatchSlow: more than kMatchKeys suffixes, or one of them has fewer than
+//                       P2 + 16 bases (its key is zero padded) -- the entry only proves `base`
+//   meta byte 3  rows   min(number of suffixes, 255)
+//   key[i]              the 16 bases that FOLLOW the first P2 bases of the i-th suffix (SA order), packed
+//                       like the reference (base j in bits [30-2j, 31-2j]); unused slots repeat key[0]
+// The longest match of a query position is  min(base + max_i lcp(query key, key[i]), bases left)  unless
+// the entry is slow or a key agrees in all 16 bases (then the suffix array decides).
+constexpr int kMatchKeys = 7;
+constexpr uint32_t kMatchSlow = 1u << 16;
+struct MatchRec {
+    uint32_t meta;
+    uint32_t key[kMatchKeys];
+};
+static_assert(sizeof(MatchRec) == 32, "MatchRec must be one 32-byte fetch");
 
 // One slot of the device K-mer hash table (the GPU form of the reference's `lut` dict,
 // SMEM/LUT.py:33-35): key -> inclusive SA interval.  Empty slot: lo < 0.
@@ -96,6 +116,8 @@ struct BlobHeader {
     int32_t flags;        // kFlagDir16: every directory entry is within 65535 rows of entry (x & ~15)
     int64_t off_rmi_err;  // int32 [rmi_err_entries]: per leaf model, max |int(prediction) - row| over the training keys
     int64_t rmi_err_entries;   // 0 = no error table (model installed from coefficients)
+    int64_t off_mtab;     // MatchRec [4^P2]
+    int64_t mtab_entries;
 };
 // The serialized header occupies GENIE_HEADER_BYTES; the struct is copied into its front.
 static_assert(sizeof(BlobHeader) <= GENIE_HEADER_BYTES, "header size");
@@ -109,6 +131,7 @@ struct DevIndex {
     const RmiModel *rmi;
     const HeadRec *dir2;   // second-level range table (global, L2-resident), or null
     const int32_t *rmi_err; // per-leaf error bounds of a natively trained RMI, or null
+    const MatchRec *mtab;  // match table, 4^P2 entries
     int32_t flags;
     int32_t n;
     int32_t K;
@@ -138,6 +161,7 @@ struct HostIndex {
     std::vector<uint32_t> dir;
     int32_t P2 = 0;
     std::vector<HeadRec> dir2;           // 4^P2 entries
+    std::vector<MatchRec> mtab;          // 4^P2 entries
     int32_t flags = 0;
     std::vector<uint32_t> lut_code;      // sorted distinct K-mers
     std::vector<int32_t> lut_lo, lut_hi;
@@ -152,7 +176,7 @@ struct HostIndex {
 };
 
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
-                     HostIndex **out);
+                     int32_t dir2_bits, HostIndex **out);
 void fill_header(const HostIndex &h, BlobHeader *hdr);
 int serialize(const HostIndex &h, void *dst, int64_t cap);
 int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t bytes, DevIndex *out);
@@ -171,6 +195,7 @@ struct genie_index {
     int32_t num_cus = 0;
     int32_t opt_lut_probe = 0;       // GENIE_OPT_LUT_PROBE
     int32_t opt_search_all = 0;      // GENIE_OPT_SEARCH_ALL
+    int32_t opt_legacy_search = 0;   // GENIE_OPT_LEGACY_SEARCH
     void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel
     void *ev_search_end = nullptr;
 };

@@ -8,6 +8,7 @@
 // Occ matrix is built -- interval search on the suffix array yields the same row intervals as
 // FM backward search (pinned by tests against the reference's own outputs).
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <new>
 
@@ -100,7 +101,7 @@ bool suffix_less(const uint8_t *codes, int64_t n, int64_t a, int64_t b)
 }  // namespace
 
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
-                     HostIndex **out)
+                     int32_t dir2_bits, HostIndex **out)
 {
     if (!codes || !out || n < 1 || n > 0x7ffffff0ll || K < 0 || K > GENIE_MAX_K) return GENIE_E_INVALID;
     if (P <= 0 || P > GENIE_MAX_DIR_BITS) P = GENIE_MAX_DIR_BITS;
@@ -172,28 +173,68 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
         }
 
         // Second-level range table: for every P2-mer the exact rows [lb, ub) whose suffix starts with it
-        // (rows sharing a prefix are contiguous).  P2 = smallest with 4^P2 >= n/2, i.e. <= 2 rows per
-        // entry on average; skipped for references too small to need it.
-        if (n >= 65536) {
+        // (rows sharing a prefix are contiguous).  P2 = smallest with 4^P2 >= n/2 (and > P), i.e. <= 2 rows
+        // per entry on average.  The match table has the same index: per P2-mer the 16-base continuations
+        // of (up to kMatchKeys of) its suffixes, in ONE 32-byte entry -- what the match-statistics kernel
+        // reads instead of searching rows.
+        {
             int P2 = P + 1;
             while (P2 < 12 && ((int64_t)1 << (2 * P2)) < n / 2) P2++;
-            if (const char *e = std::getenv("GENIE_DIR2_BITS")) {       // build-time tuning knob
-                const int v = std::atoi(e);
-                if (v > P && v <= 12) P2 = v;
-            }
+            if (dir2_bits > P && dir2_bits <= 12) P2 = dir2_bits;       // build-time tuning (genie_index_create_ex)
             h->P2 = P2;
             const int64_t nb2 = (int64_t)1 << (2 * P2);
             h->dir2.assign((size_t)nb2, HeadRec{0, 0, 0});
+            h->mtab.assign((size_t)nb2, MatchRec{0, {0, 0, 0, 0, 0, 0, 0}});
+            std::vector<uint32_t> cnt((size_t)nb2, 0);
             for (int64_t r = 0; r < rows; r++) {
                 const int64_t s = h->sa0[(size_t)r];
                 if (n - s < P2) continue;
-                HeadRec &e = h->dir2[(size_t)code_at64(codes, s, P2)];
+                const uint64_t c = code_at64(codes, s, P2);
+                HeadRec &e = h->dir2[(size_t)c];
                 if ((e.meta & ~kHeadShort) == 0) {
                     e.lb = (uint32_t)r;
                     e.key = h->sarec[(size_t)r].key;
                     e.meta = (n - s < P + 32) ? kHeadShort : 0;
                 }
                 e.meta++;
+                MatchRec &m = h->mtab[(size_t)c];
+                const uint32_t k = cnt[(size_t)c]++;
+                if (k < (uint32_t)kMatchKeys) {
+                    uint32_t key = 0;
+                    for (int j = 0; j < 16; j++) {
+                        const int64_t p = s + P2 + j;
+                        key |= (p < n ? (uint32_t)codes[p] : 0u) << (30 - 2 * j);
+                    }
+                    m.key[k] = key;
+                } else {
+                    m.meta |= kMatchSlow;
+                }
+                if (n - s < P2 + 16) m.meta |= kMatchSlow;
+            }
+            // which t-mers (t < P2) occur anywhere in the reference, its last bases included
+            std::vector<std::vector<uint8_t>> occ((size_t)P2);
+            for (int t = 1; t < P2; t++) {
+                occ[(size_t)t].assign((size_t)1 << (2 * t), 0);
+                if (t > n) continue;
+                uint64_t code = 0;
+                const uint64_t mask = ((uint64_t)1 << (2 * t)) - 1;
+                for (int64_t i = 0; i < n; i++) {
+                    code = ((code << 2) | codes[i]) & mask;
+                    if (i >= t - 1) occ[(size_t)t][(size_t)code] = 1;
+                }
+            }
+            for (int64_t c = 0; c < nb2; c++) {
+                MatchRec &m = h->mtab[(size_t)c];
+                const uint32_t k = cnt[(size_t)c];
+                if (k == 0) {
+                    int t = P2 - 1;
+                    while (t >= 1 && !occ[(size_t)t][(size_t)((uint64_t)c >> (2 * (P2 - t)))]) t--;
+                    m.meta = (uint32_t)t;                                // lmask = 0, flags = 0, rows = 0
+                } else {
+                    for (uint32_t i = k; i < (uint32_t)kMatchKeys; i++) m.key[i] = m.key[0];
+                    const uint32_t slow = m.meta & kMatchSlow;                 // a slow entry proves P2 bases, no more
+                    m.meta = slow | (uint32_t)P2 | (slow ? 0u : 0x1Fu << 8) | ((k < 255 ? k : 255u) << 24);
+                }
             }
         }
 
@@ -276,6 +317,9 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->off_rmi_err = off;
     hdr->rmi_err_entries = (int64_t)h.rmi_err.size();
     off = align_up(off + (int64_t)std::max<size_t>(h.rmi_err.size(), 1) * 4);
+    hdr->off_mtab = off;
+    hdr->mtab_entries = (int64_t)h.mtab.size();
+    off = align_up(off + (int64_t)h.mtab.size() * (int64_t)sizeof(MatchRec));
     hdr->total_bytes = off;
 }
 
@@ -430,16 +474,57 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
     if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * sizeof(HeadRec));
     if (!h.rmi_err.empty()) memcpy(p + hdr.off_rmi_err, h.rmi_err.data(), h.rmi_err.size() * 4);
+    memcpy(p + hdr.off_mtab, h.mtab.data(), h.mtab.size() * sizeof(MatchRec));
     return GENIE_OK;
+}
+
+// A section [off, off + count * elem) must lie inside the image after the header, 16-byte aligned.
+static bool section_ok(const BlobHeader &hdr, int64_t bytes, int64_t off, int64_t count, int64_t elem)
+{
+    if (off < GENIE_HEADER_BYTES || (off & 15) != 0 || count < 0 || elem <= 0) return false;
+    if (count > (INT64_MAX - off) / elem) return false;
+    const int64_t end = off + count * elem;
+    return end <= hdr.total_bytes && end <= bytes;
 }
 
 int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t bytes, DevIndex *out)
 {
     if (hdr.magic != kMagic || hdr.version != kBlobVersion || hdr.header_bytes != GENIE_HEADER_BYTES)
         return GENIE_E_BAD_BLOB;
-    if (bytes < hdr.total_bytes || hdr.P < 1 || hdr.P > GENIE_MAX_DIR_BITS || hdr.n < 1) return GENIE_E_BAD_BLOB;
+    if (bytes < hdr.total_bytes || hdr.total_bytes < GENIE_HEADER_BYTES) return GENIE_E_BAD_BLOB;
+    if (hdr.P < 1 || hdr.P > GENIE_MAX_DIR_BITS || hdr.n < 1 || hdr.n > 0x7ffffff0ll) return GENIE_E_BAD_BLOB;
+    if (hdr.K < 0 || hdr.K > GENIE_MAX_K) return GENIE_E_BAD_BLOB;
     if (hdr.dir_entries != ((int64_t)1 << (2 * hdr.P)) + 1) return GENIE_E_BAD_BLOB;
-    if (hdr.P2 != 0 && (hdr.P2 <= hdr.P || hdr.P2 > 12 || hdr.dir2_entries != ((int64_t)1 << (2 * hdr.P2)))) return GENIE_E_BAD_BLOB;
+    if (hdr.P2 <= hdr.P || hdr.P2 > 12 || hdr.dir2_entries != ((int64_t)1 << (2 * hdr.P2)) ||
+        hdr.mtab_entries != hdr.dir2_entries)
+        return GENIE_E_BAD_BLOB;
+    if (hdr.ref_recs < (hdr.n + 31) / 32 + 3) return GENIE_E_BAD_BLOB;
+    // every section inside the image (a truncated or corrupt image must not become a wild device pointer)
+    if (!section_ok(hdr, bytes, hdr.off_sa, hdr.n + 1, sizeof(SaRec)) ||
+        !section_ok(hdr, bytes, hdr.off_ref, hdr.ref_recs, sizeof(RefRec)) ||
+        !section_ok(hdr, bytes, hdr.off_dir, hdr.dir_entries, 4) ||
+        !section_ok(hdr, bytes, hdr.off_lut, hdr.lut_slots, sizeof(LutSlot)) ||
+        !section_ok(hdr, bytes, hdr.off_rmi, hdr.rmi_models, sizeof(RmiModel)) ||
+        !section_ok(hdr, bytes, hdr.off_dir2, hdr.dir2_entries, sizeof(HeadRec)) ||
+        !section_ok(hdr, bytes, hdr.off_rmi_err, hdr.rmi_err_entries, 4) ||
+        !section_ok(hdr, bytes, hdr.off_mtab, hdr.mtab_entries, sizeof(MatchRec)))
+        return GENIE_E_BAD_BLOB;
+    // the hash table needs an empty slot for every probe sequence to end
+    if (hdr.lut_keys < 0 || hdr.lut_slots < hdr.lut_keys + 1 || hdr.lut_slots > 0xFFFFFFFFll) return GENIE_E_BAD_BLOB;
+    // RMI level table: level l has rmi_size[l] models at rmi_off[l]; level l + 1 has rmi_scale[l] of them
+    if (hdr.nlev < 0 || hdr.nlev > GENIE_MAX_RMI_LEVELS) return GENIE_E_BAD_BLOB;
+    if (hdr.nlev > 0) {
+        if (hdr.rmi_off[0] != 0 || hdr.rmi_size[0] != 1) return GENIE_E_BAD_BLOB;
+        for (int l = 0; l < hdr.nlev; l++) {
+            if (hdr.rmi_size[l] < 1 || hdr.rmi_scale[l] < 1) return GENIE_E_BAD_BLOB;
+            if (hdr.rmi_off[l + 1] != hdr.rmi_off[l] + hdr.rmi_size[l]) return GENIE_E_BAD_BLOB;
+            if (l + 1 < hdr.nlev && hdr.rmi_size[l + 1] != hdr.rmi_scale[l]) return GENIE_E_BAD_BLOB;
+        }
+        if ((int64_t)hdr.rmi_off[hdr.nlev] != hdr.rmi_models) return GENIE_E_BAD_BLOB;
+        if (hdr.rmi_err_entries != 0 && hdr.rmi_err_entries != hdr.rmi_size[hdr.nlev - 1]) return GENIE_E_BAD_BLOB;
+    } else if (hdr.rmi_models != 0 || hdr.rmi_err_entries != 0) {
+        return GENIE_E_BAD_BLOB;
+    }
     if ((reinterpret_cast<uintptr_t>(d_blob) & 15) != 0) return GENIE_E_INVALID;
     const uint8_t *p = (const uint8_t *)d_blob;
     memset(out, 0, sizeof(*out));
@@ -448,7 +533,8 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->dir = (const uint32_t *)(p + hdr.off_dir);
     out->lut = (const LutSlot *)(p + hdr.off_lut);
     out->rmi = (const RmiModel *)(p + hdr.off_rmi);
-    out->dir2 = hdr.P2 > 0 ? (const HeadRec *)(p + hdr.off_dir2) : nullptr;
+    out->dir2 = (const HeadRec *)(p + hdr.off_dir2);
+    out->mtab = (const MatchRec *)(p + hdr.off_mtab);
     out->P2 = hdr.P2;
     out->flags = hdr.flags;
     out->rmi_err = hdr.rmi_err_entries > 0 ? (const int32_t *)(p + hdr.off_rmi_err) : nullptr;

@@ -442,6 +442,7 @@ __device__ __forceinline__ bool load_and_pack(const uint8_t *src, int L, int Lma
 }
 
 #include "short_read_kernel.inc"
+#include "match_table_kernel.inc"
 
 // ------------------------------------------------------------------ K1: batched exact_match_back_prop
 __global__ void __launch_bounds__(256) sa_interval_kernel(DevIndex ix, const uint8_t *__restrict__ pats,
@@ -595,6 +596,8 @@ struct Geometry {
     int sampled;     // sampled search (match_stats_sampled_kernel) with this work-list capacity, 0 = not used
     int grp, sshift; // its reads per wave iteration and log2 of the sampling stride
     int win;         // long reads: window of the sampled search (match_stats_sampled_long_kernel), 0 = not used
+    int mt;          // match-table kernel (reads of at most 255 bases): slow-list capacity, 0 = not used
+    uint32_t recip;  // its ceil(2^32 / max_len)
     int pair;        // narrow fixed-length batch whose last slot holds <= 32 positions: two reads per wave iteration
     int ns;          // position slots per chunk in K_A (1..4)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
@@ -680,6 +683,31 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
     }
     g->sampled = 0;
     g->win = 0;
+    g->mt = 0;
+    g->recip = 0;
+    if (!g->wide && max_len > 0 && !ix->opt_legacy_search) {
+        // match-table kernel: `grp` reads per wave iteration (about 768 positions = four passes of
+        // 3 x 64), eight waves per block, nothing block-wide in LDS
+        const int grp = std::min(kSampMaxG, std::max(1, 768 / max_len));
+        const int wl_cap = grp * max_len;
+        const int list_bytes = (wl_cap * 2 + 15) & ~15;
+        const int pw = grp * g->qp_words * 8 + 32 + 48 + ((grp * g->fwd_stride + 15) & ~15) + 2 * list_bytes;
+        const int wpb = 8;
+        g->mt = wl_cap;
+        g->grp = grp;
+        g->recip = max_len >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)max_len - 1) / (uint64_t)max_len) : 0u;
+        g->lds = wpb * pw;
+        g->leaf_in_lds = 0;
+        g->block = wpb * kWave;
+        int bpc = std::min(lds_cap / g->lds, 32 / wpb);
+        if (bpc < 1) bpc = 1;
+        long long gr = (long long)cus * bpc;
+        const long long need2 = (N + (long long)wpb * grp - 1) / ((long long)wpb * grp);
+        if (gr > need2) gr = need2;
+        if (gr < 1) gr = 1;
+        g->grid = (int)gr;
+        return GENIE_OK;
+    }
     if (g->wide && (d.flags & kFlagDir16) && !ix->opt_search_all) {
         // sampled search for long reads: one wave per read, windows of 704 positions
         const int win = 704;
@@ -820,7 +848,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                                   : (probe ? match_stats_kernel<MODE, NS, WIDE, false, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, false, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
-    if (WIDE && g.win) {
+    if (!WIDE && g.mt) {
+        auto km = match_table_kernel<MODE>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
+                           reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
+                           g.grp, g.mt, g.recip);
+    } else if (WIDE && g.win) {
         auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(kl, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,

@@ -39,22 +39,21 @@ class GenieIndex:
 
     # ------------------------------------------------------------------ construction (host)
     @classmethod
-    def build(cls, codes, K, dir_bits=7, sa_one_based=None):
+    def build(cls, codes, K, dir_bits=7, sa_one_based=None, table_bits=0):
         """codes: uint8 array of base codes 0..3; K: LUT / RMI key size (0 = none);
-        sa_one_based: adopt this suffix array (reference JSON convention) instead of building."""
+        sa_one_based: adopt this suffix array (reference JSON convention) instead of building;
+        table_bits: P2 of the per-P2-mer tables (0 = automatic), a tuning knob only."""
         codes = np.ascontiguousarray(codes, np.uint8)
         self = cls()
         u8p = C.POINTER(C.c_uint8)
-        if sa_one_based is None:
-            rc = N.lib().genie_index_create(codes.ctypes.data_as(u8p), codes.size, int(K), int(dir_bits),
-                                            C.byref(self._h))
-        else:
+        sa_p = None
+        if sa_one_based is not None:
             sa = np.ascontiguousarray(sa_one_based, np.int32)
             if sa.size != codes.size + 1:
                 raise ValueError("suffix array must have n+1 rows")
-            rc = N.lib().genie_index_create_from_sa(codes.ctypes.data_as(u8p), codes.size,
-                                                    sa.ctypes.data_as(C.POINTER(C.c_int32)), int(K), int(dir_bits),
-                                                    C.byref(self._h))
+            sa_p = sa.ctypes.data_as(C.POINTER(C.c_int32))
+        rc = N.lib().genie_index_create_ex(codes.ctypes.data_as(u8p), codes.size, sa_p, int(K), int(dir_bits),
+                                           int(table_bits), C.byref(self._h))
         N.check(rc, "genie_index_create")
         return self
 

@@ -98,6 +98,12 @@ int genie_index_create(const uint8_t *codes, int64_t n, int32_t K, int32_t dir_b
 int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K,
                                int32_t dir_bits, genie_index **out);
 
+/* genie_index_create / _from_sa (sa_one_based may be NULL) with the size of the per-P2-mer tables chosen by
+ * the caller: table_bits = P2 in (dir_bits, 12], 0 = automatic (smallest P2 with 4^P2 >= n/2).  A tuning
+ * knob of the index image only: results do not depend on it. */
+int genie_index_create_ex(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t dir_bits,
+                          int32_t table_bits, genie_index **out);
+
 /* Install an RMI model (RMI.models after RMI.fit, SMEM/RMI.py:10-50): `nlev` levels, level l has
  * sizes[l] linear models (sizes[0] == 1) and the clamp scale scales[l] (= experts + [1], RMI.py:54);
  * coef / icpt are the per-level arrays concatenated.  Must precede serialize / to_device. */
@@ -214,7 +220,7 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  * table for every read position before the suffix-array search.  Results are identical either
  * way; on MI355X the LDS-staged P-mer directory already narrows a position to a handful of rows,
  * so the extra probe only costs time (measured: DESIGN.md) and is off by default. */
-enum { GENIE_OPT_LUT_PROBE = 1, GENIE_OPT_SEARCH_ALL = 2 };
+enum { GENIE_OPT_LUT_PROBE = 1, GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_LEGACY_SEARCH = 3 };
 /* GENIE_OPT_SEARCH_ALL (default 0): the matching statistics fwd[] are non-decreasing along a read, so by
  * default reads are searched at every 4th position first and only the gaps whose two ends disagree are
  * searched inside (identical results; 1.6x to 3.7x faster on reads that match the reference end to end,

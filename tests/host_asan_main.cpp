@@ -11,7 +11,7 @@ int main() {
         if (n == 1000) for (size_t i = 0; i < 400; i++) codes[i] = i % 6 < 2 ? 3 : (i % 6 < 3 ? 0 : 1);   // repeats
         for (int K : {0, 3, 8, 15}) {
             HostIndex *h = nullptr;
-            int rc = build_host_index(codes.data(), n, nullptr, K, 7, &h);
+            int rc = build_host_index(codes.data(), n, nullptr, K, 7, n == 17 ? 9 : 0, &h);
             if (rc) { printf("n=%lld K=%d rc=%d\n", (long long)n, K, rc); continue; }
             if (K > 0 && n >= K) {
                 int32_t ex[2] = {10, 100};
@@ -23,6 +23,11 @@ int main() {
             std::vector<uint8_t> blob((size_t)hdr.total_bytes);
             rc = serialize(*h, blob.data(), (int64_t)blob.size());
             printf("n=%lld K=%d serialize rc=%d bytes=%lld P2=%d\n", (long long)n, K, rc, (long long)hdr.total_bytes, hdr.P2);
+            // the image validator on the image just written, whole and truncated (host pointer stands in for the device's)
+            DevIndex dev;
+            int ok = dev_index_from_header(hdr, blob.data(), (int64_t)blob.size(), &dev);
+            int cut = dev_index_from_header(hdr, blob.data(), (int64_t)blob.size() - 1, &dev);
+            if (ok != 0 || cut == 0) { printf("validator: ok=%d cut=%d\n", ok, cut); return 1; }
             delete h;
         }
     }

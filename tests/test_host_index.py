@@ -117,7 +117,7 @@ def test_reference_checked_in_fixtures(pkg):
 
 
 # ------------------------------------------------------------------ image + prefix directory
-HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqiiqq")
+HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqiiqqqq")
 
 
 def _parse(img):
@@ -125,10 +125,11 @@ def _parse(img):
     keys = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
             "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
     h = dict(zip(keys, f[:18]))
-    h["padtail"] = list(f[-14:-6])
-    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-6], f[-5], f[-4]
-    h["flags"] = f[-3]
-    h["off_rmi_err"], h["rmi_err_entries"] = f[-2], f[-1]
+    h["padtail"] = list(f[-16:-8])
+    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-8], f[-7], f[-6]
+    h["flags"] = f[-5]
+    h["off_rmi_err"], h["rmi_err_entries"] = f[-4], f[-3]
+    h["off_mtab"], h["mtab_entries"] = f[-2], f[-1]
     return h
 
 
@@ -306,5 +307,114 @@ def test_second_level_range_table(pkg):
     assert (pairs[~present, 0] >= pairs[~present, 1]).all()
     # contiguity: the rows between first and last all carry the same P2-mer
     assert (last[present] - first[present] + 1 == np.bincount(c, minlength=4 ** P2)[present]).all()
-    # small references carry no second-level table
-    assert _parse(pkg.GenieIndex.build(ref[:5000], 8).serialize().numpy())["P2"] == 0
+    # small references get the smallest table (P2 = P + 1); the table size can be chosen at build time
+    assert _parse(pkg.GenieIndex.build(ref[:5000], 8).serialize().numpy())["P2"] == 8
+    assert _parse(pkg.GenieIndex.build(ref[:5000], 8, table_bits=9).serialize().numpy())["P2"] == 9
+
+
+def _match_table(img, h):
+    return np.frombuffer(bytes(img[h["off_mtab"]:h["off_mtab"] + 32 * h["mtab_entries"]]),
+                         np.dtype([("meta", "<u4"), ("key", "<u4", (7,))]))
+
+
+@pytest.mark.parametrize("case", ["syn10k", "tail_A", "tiny", "repeat"])
+def test_match_table_against_brute_force(pkg, case):
+    """MatchRec per P2-mer (genie_internal.h): base / lmask / slow flag / row count and the 16-base
+    continuations of its suffixes, against a direct enumeration of the reference's substrings."""
+    rng = np.random.default_rng(77)
+    if case == "syn10k":
+        ref = rng.integers(0, 4, 10_000).astype(np.uint8)
+    elif case == "tail_A":                       # the reference ends in A's: cut-short suffixes look like padding
+        ref = np.concatenate([rng.integers(0, 4, 3000), np.zeros(40, np.int64)]).astype(np.uint8)
+    elif case == "tiny":
+        ref = rng.integers(0, 4, 13).astype(np.uint8)
+    else:                                        # a tandem repeat: one P2-mer with many suffixes
+        ref = np.concatenate([np.tile([0, 1, 2, 3, 3, 1], 60), rng.integers(0, 4, 2000)]).astype(np.uint8)
+    n = len(ref)
+    ix = pkg.GenieIndex.build(ref, 6)
+    img = ix.serialize().numpy()
+    h = _parse(img)
+    P2 = h["P2"]
+    assert h["mtab_entries"] == 4 ** P2 == h["dir2_entries"]
+    mt = _match_table(img, h)
+    base, lmask = mt["meta"] & 0xFF, (mt["meta"] >> 8) & 0xFF
+    slow, rows = (mt["meta"] >> 16) & 1, mt["meta"] >> 24
+    s = "".join("ACGT"[c] for c in ref)
+    occ = [set()] + [{s[i:i + t] for i in range(n - t + 1)} for t in range(1, P2 + 1)]
+    sa0 = ix.suffix_array().astype(np.int64) - 1
+    by_code = {}
+    for st in sa0:                               # suffix-array order
+        if n - st >= P2:
+            by_code.setdefault(s[st:st + P2], []).append(int(st))
+    code_of = lambda t: int("".join(str("ACGT".index(c)) for c in t), 4)        # noqa: E731
+    seen = 0
+    for mer, starts in by_code.items():
+        c = code_of(mer)
+        seen += 1
+        cut = any(n - st < P2 + 16 for st in starts)
+        assert base[c] == P2 and rows[c] == min(len(starts), 255)
+        assert slow[c] == int(len(starts) > 7 or cut)
+        assert lmask[c] == (0 if slow[c] else 0x1F)
+        keys = []
+        for st in starts[:7]:
+            k = 0
+            for j in range(16):
+                k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (30 - 2 * j)
+            keys.append(k)
+        keys += [keys[0]] * (7 - len(keys))
+        assert mt["key"][c].tolist() == keys, mer
+    absent = np.nonzero(base < P2)[0]
+    assert len(absent) == 4 ** P2 - seen
+    for c in (absent if len(absent) < 3000 else rng.choice(absent, 3000, replace=False)):
+        mer = "".join("ACGT"[(int(c) >> (2 * (P2 - 1 - j))) & 3] for j in range(P2))
+        t = max([t for t in range(1, P2) if mer[:t] in occ[t]], default=0)
+        assert base[c] == t and slow[c] == 0 and rows[c] == 0, mer
+
+
+def test_corrupt_image_is_rejected(pkg):
+    """genie_index_open validates every section of the image header: a truncated or corrupt image must
+    come back as GENIE_E_BAD_BLOB, not as device pointers outside the allocation.  (Host-side check:
+    the device pointer is never dereferenced by open.)"""
+    import ctypes as C
+    lib = pkg._native.lib()
+    ref = np.random.default_rng(5).integers(0, 4, 3000).astype(np.uint8)
+    ix = pkg.GenieIndex.build(ref, 6)
+    ix.train_rmi([10])
+    img = ix.serialize().numpy().copy()
+    h = _parse(img)
+    fake_dev = C.c_void_p(0x7f0000000000)                         # 16-byte aligned, never touched
+
+    def try_open(buf, nbytes=None):
+        out = C.c_void_p(None)
+        rc = lib.genie_index_open(buf.ctypes.data_as(C.c_void_p), fake_dev, len(buf) if nbytes is None else nbytes, 0,
+                                  C.byref(out))
+        if rc == 0:
+            lib.genie_index_destroy(out)
+        return rc
+
+    assert try_open(img) == 0
+    assert try_open(img, h["total_bytes"] - 256) == -8            # truncated
+    fields = {name: HDR.unpack(bytes(img[:HDR.size])) for name in ["ok"]}["ok"]
+    names = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
+             "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
+    pos = {k: i for i, k in enumerate(names)}
+    tail = {"off_dir2": -8, "dir2_entries": -7, "P2": -6, "off_rmi_err": -4, "rmi_err_entries": -3, "off_mtab": -2,
+            "mtab_entries": -1}
+
+    def corrupt(**kw):
+        f = list(fields)
+        for k, v in kw.items():
+            f[pos[k] if k in pos else len(f) + tail[k]] = v
+        buf = img.copy()
+        buf[:HDR.size] = np.frombuffer(HDR.pack(*f), np.uint8)
+        return try_open(buf)
+
+    big = h["total_bytes"]
+    for bad in (dict(off_sa=big), dict(off_ref=big - 16), dict(off_dir=big + 4096), dict(off_lut=-256),
+                dict(off_rmi=big), dict(off_dir2=big - 64), dict(off_mtab=big - 64), dict(off_rmi_err=big),
+                dict(off_sa=h["off_sa"] + 4),                     # misaligned
+                dict(lut_slots=0), dict(lut_slots=h["lut_keys"]), dict(lut_slots=1 << 40), dict(n=h["n"] + 10 ** 7),
+                dict(K=17), dict(K=-1), dict(nlev=5), dict(nlev=-1), dict(rmi_models=h["rmi_models"] + 1),
+                dict(rmi_err_entries=h["rmi_err_entries"] + 1), dict(P2=h["P"]), dict(P2=13),
+                dict(mtab_entries=h["mtab_entries"] - 1), dict(dir2_entries=4), dict(ref_recs=1), dict(version=6)):
+        assert corrupt(**bad) == -8, bad
