@@ -32,17 +32,21 @@ constexpr uint32_t kHeadShort = 0x80000000u;
 constexpr int32_t kFlagDir16 = 1;
 
 // Match-table entry (one per P2-mer, 32 bytes = ONE aligned fetch): everything the match-statistics
-// kernel needs to know about the suffixes that start with this P2-mer, without their order or rows.
+// kernel needs to know about the suffixes that start with this P2-mer.
 //   meta byte 0  base   P2 when the P2-mer occurs, else the longest prefix of it (0 .. P2-1) that occurs
 //                       anywhere in the reference (also inside its last P2-1 bases)
-//   meta byte 1  lmask  0x1F when the P2-mer occurs and the entry is not slow, else 0:  match >= base + (lcp & lmask)
+//   meta byte 1  lmask  0x1F when the P2-mer occurs and the entry is not slow, else 0:
+//                       longest match >= base + (lcp & lmask)
 //   meta byte 2  flags  kMatchSlow: more than kMatchKeys suffixes, or one of them has fewer than
 //                       P2 + 16 bases (its key is zero padded) -- the entry only proves `base`
 //   meta byte 3  rows   min(number of suffixes, 255)
-//   key[i]              the 16 bases that FOLLOW the first P2 bases of the i-th suffix (SA order), packed
-//                       like the reference (base j in bits [30-2j, 31-2j]); unused slots repeat key[0]
+//   key[i]              the 16 bases that FOLLOW the first P2 bases of the i-th of them (suffix-array order, so
+//                       ascending), packed like the reference (base j in bits [30-2j, 31-2j]); unused slots
+//                       repeat key[0].  meta + key[0..2] are the first 16 bytes: most positions need no more
+//                       (three or fewer suffixes, or a query key that does not exceed key[2]).
 // The longest match of a query position is  min(base + max_i lcp(query key, key[i]), bases left)  unless
-// the entry is slow or a key agrees in all 16 bases (then the suffix array decides).
+// the entry is slow or a key agrees in all 16 bases with more of the read left: then the suffix-array
+// rows whose keys agree (or, for a slow entry, a search of all its rows) decide.
 constexpr int kMatchKeys = 7;
 constexpr uint32_t kMatchSlow = 1u << 16;
 struct MatchRec {
@@ -196,6 +200,8 @@ struct genie_index {
     int32_t opt_lut_probe = 0;       // GENIE_OPT_LUT_PROBE
     int32_t opt_search_all = 0;      // GENIE_OPT_SEARCH_ALL
     int32_t opt_legacy_search = 0;   // GENIE_OPT_LEGACY_SEARCH
+    int32_t opt_group_positions = 0; // GENIE_OPT_GROUP_POSITIONS (0 = default)
+    int32_t opt_search_only = 0;     // GENIE_OPT_SEARCH_ONLY
     void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel
     void *ev_search_end = nullptr;
 };

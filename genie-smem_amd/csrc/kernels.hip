@@ -686,17 +686,14 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
     g->mt = 0;
     g->recip = 0;
     if (!g->wide && max_len > 0 && !ix->opt_legacy_search) {
-        // match-table kernel: `grp` reads per wave iteration (about 768 positions = four passes of
+        // match-table kernel: `grp` reads per wave iteration (about kMtTarget positions: a few passes of
         // 3 x 64), eight waves per block, nothing block-wide in LDS
-        const int grp = std::min(kSampMaxG, std::max(1, 768 / max_len));
-        const int wl_cap = grp * max_len;
-        const int list_bytes = (wl_cap * 2 + 15) & ~15;
-        const int pw = grp * g->qp_words * 8 + 32 + 48 + ((grp * g->fwd_stride + 15) & ~15) + 2 * list_bytes;
+        const int grp = std::min(std::min(kMtMaxG, kWave / mt_pack_dwords(max_len) * 4), std::max(1, (ix->opt_group_positions > 0 ? ix->opt_group_positions : kMtTarget) / max_len));
         const int wpb = 8;
-        g->mt = wl_cap;
+        g->mt = grp * max_len;
         g->grp = grp;
         g->recip = max_len >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)max_len - 1) / (uint64_t)max_len) : 0u;
-        g->lds = wpb * pw;
+        g->lds = wpb * mt_wave_bytes(grp, max_len, g->qp_recs, g->fwd_stride);
         g->leaf_in_lds = 0;
         g->block = wpb * kWave;
         int bpc = std::min(lds_cap / g->lds, 32 / wpb);
@@ -849,11 +846,11 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     if (!WIDE && g.mt) {
-        auto km = match_table_kernel<MODE>;
+        auto km = match_table_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-        hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
-                           reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
-                           g.grp, g.mt, g.recip);
+        hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
+                           g.grp, g.max_len, g.recip, (long long)sizeof(MatchRec) << (2 * ix->dev.P2));
     } else if (WIDE && g.win) {
         auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
@@ -874,6 +871,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                        g.blocks_a);
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
+    if (ix->opt_search_only) return GENIE_OK;        // GENIE_OPT_SEARCH_ONLY: timing experiments, workspace only
     auto kb = traverse_kernel<MODE, WIDE>;
     const int tb = 256;
     const int lds_b = WIDE ? 0 : tb * g.fwd_stride;

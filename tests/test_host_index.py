@@ -342,10 +342,11 @@ def test_match_table_against_brute_force(pkg, case):
     s = "".join("ACGT"[c] for c in ref)
     occ = [set()] + [{s[i:i + t] for i in range(n - t + 1)} for t in range(1, P2 + 1)]
     sa0 = ix.suffix_array().astype(np.int64) - 1
-    by_code = {}
-    for st in sa0:                               # suffix-array order
+    by_code, first_row = {}, {}
+    for row, st in enumerate(sa0):               # suffix-array order
         if n - st >= P2:
             by_code.setdefault(s[st:st + P2], []).append(int(st))
+            first_row.setdefault(s[st:st + P2], row)
     code_of = lambda t: int("".join(str("ACGT".index(c)) for c in t), 4)        # noqa: E731
     seen = 0
     for mer, starts in by_code.items():
@@ -362,6 +363,7 @@ def test_match_table_against_brute_force(pkg, case):
                 k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (30 - 2 * j)
             keys.append(k)
         keys += [keys[0]] * (7 - len(keys))
+        assert slow[c] or keys[:len(starts)] == sorted(keys[:len(starts)])      # ascending: suffix-array order
         assert mt["key"][c].tolist() == keys, mer
     absent = np.nonzero(base < P2)[0]
     assert len(absent) == 4 ** P2 - seen

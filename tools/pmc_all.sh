@@ -16,7 +16,7 @@ O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/pmc_all"
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(O+"/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        m=re.search(r"(match_stats\w*kernel|traverse_kernel|interval_kernel)", r["Kernel_Name"])
+        m=re.search(r"(match_table_kernel|match_stats\w*kernel|traverse_kernel|interval_kernel)", r["Kernel_Name"])
         if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,d in agg.items():
     print(k)

@@ -19,6 +19,6 @@ for f in sorted(glob.glob(O+"/p*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        if "match_stats" in k: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "match_table" in k or "match_stats" in k: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c,v in agg.items(): print(c, sum(v)/len(v), len(v))
 PY
