@@ -286,6 +286,13 @@ int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len)
     return find_smems_workspace_bytes(N, max_len);
 }
 
+int genie_find_smems_workspace_rows(int32_t max_len, int32_t *row_bytes4)
+{
+    if (max_len < 0 || max_len > GENIE_MAX_READ_LEN || !row_bytes4) return GENIE_E_INVALID;
+    find_smems_workspace_rows(max_len, row_bytes4);
+    return GENIE_OK;
+}
+
 int64_t genie_compact_tmp_bytes(int64_t N) { return N < 0 ? (int64_t)GENIE_E_INVALID : compact_tmp_bytes(N); }
 
 int genie_compact_smems(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap,
@@ -314,6 +321,14 @@ int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int3
     int rc = ready(ix);
     if (rc) return rc;
     return find_smems_geometry(ix, mode, max_len, grid, block, lds_bytes);
+}
+
+int genie_search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    if (mode < GENIE_MODE_BWA || mode > GENIE_MODE_RMI) return GENIE_E_INVALID;
+    return search_kernel_name(ix, mode, max_len, buf, cap);
 }
 
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value)

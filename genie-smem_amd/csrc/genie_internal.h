@@ -229,6 +229,8 @@ int launch_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, 
                   int32_t *d_positions, int64_t cap, void *d_tmp, int64_t tmp_bytes, void *stream);
 int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
                         int32_t *lds_bytes);
+void find_smems_workspace_rows(int32_t max_len, int32_t out[4]);
+int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap);
 void set_hip_error(const char *what, int code);
 const char *last_hip_error();
 }  // namespace genie

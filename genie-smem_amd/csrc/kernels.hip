@@ -956,7 +956,34 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
     return GENIE_OK;
 }
 
+// Name of the match-statistics kernel the plan picks (as rocprofv3 prints it, without the argument list).
+int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap)
+{
+    Geometry g;
+    int rc = plan_find_smems(ix, mode, max_len, true, 1ll << 40, &g);
+    if (rc) return rc;
+    char tmp[160];
+    if (g.mt) snprintf(tmp, sizeof tmp, "match_table_kernel");
+    else if (g.win) snprintf(tmp, sizeof tmp, "match_stats_sampled_long_kernel<%d, %s>", mode, ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false");
+    else if (g.sampled) snprintf(tmp, sizeof tmp, "match_stats_sampled_kernel<%d, %s, %d>", mode, ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false", g.grp == 5 ? 5 : 0);
+    else snprintf(tmp, sizeof tmp, "match_stats_kernel<%d, %d, %s, %s, %s>", mode, g.ns, g.wide ? "true" : "false", g.pair ? "true" : "false",
+                  ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false");
+    if (!buf || cap < (int)strlen(tmp) + 1) return GENIE_E_CAPACITY;
+    memcpy(buf, tmp, strlen(tmp) + 1);
+    return GENIE_OK;
+}
+
 int64_t find_smems_workspace_bytes(int64_t N, int32_t max_len) { return workspace_bytes_for(N, max_len); }
+
+void find_smems_workspace_rows(int32_t max_len, int32_t out[4])
+{
+    Geometry g;
+    shape_for(max_len, &g);
+    out[0] = g.fwd_stride;
+    out[1] = g.qp_recs;
+    out[2] = g.hm_words;
+    out[3] = g.kj_row * (g.wide ? 4 : 2);
+}
 
 static int launch_find_any(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
                            int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots,

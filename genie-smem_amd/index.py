@@ -325,6 +325,18 @@ class GenieIndex:
     def set_option(self, option, value):
         N.check(N.lib().genie_index_set_option(self._h, int(option), int(value)), "genie_index_set_option")
 
+    @staticmethod
+    def workspace_shape(max_len):
+        """Per-read rows of the find_smems workspace (bytes / counts), for traffic accounting."""
+        out = (C.c_int32 * 4)()
+        N.check(N.lib().genie_find_smems_workspace_rows(int(max_len), out), "genie_find_smems_workspace_rows")
+        return {"fwd_stride": out[0], "qp_recs": out[1], "hm_words": out[2], "kj_row_bytes": out[3]}
+
+    def search_kernel_name(self, mode, max_len):
+        buf = C.create_string_buffer(160)
+        N.check(N.lib().genie_search_kernel_name(self._h, N.MODES[mode], int(max_len), buf, 160), "genie_search_kernel_name")
+        return buf.value.decode()
+
     def launch_info(self, mode, max_len):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
         N.check(N.lib().genie_launch_info(self._h, N.MODES[mode], int(max_len), C.byref(g), C.byref(b), C.byref(l)),

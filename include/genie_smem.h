@@ -183,6 +183,10 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
  * bytes (matching statistics, packed reads, hit masks and emitted (start, end) pairs handed between
  * the kernels of the pipeline). */
 int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len);
+/* Per-read rows of that workspace, for traffic accounting: out[0] = bytes of a matching-statistics (fwd) row,
+ * out[1] = 16-byte packed-read records, out[2] = 8-byte hit-mask words (+1: longest match), out[3] = bytes of
+ * the emitted (start, end) pair row. */
+int genie_find_smems_workspace_rows(int32_t max_len, int32_t *row_bytes4);
 int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
                      int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
                      int32_t *d_slots, int32_t cap, int32_t *d_status, void *d_workspace, int64_t workspace_bytes,
@@ -237,6 +241,10 @@ int genie_index_set_stage_events(genie_index *ix, void *ev_search_begin, void *e
 /* Launch geometry actually used by genie_find_smems for (mode, max read length): for reports. */
 int genie_launch_info(const genie_index *ix, int32_t mode, int32_t max_len, int32_t *grid, int32_t *block,
                       int32_t *lds_bytes);
+
+/* Name of the match-statistics (dominant) kernel genie_find_smems launches for (mode, max read length), as a
+ * profiler prints it without the argument list: for reports that look the kernel up in a rocprofv3 trace. */
+int genie_search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap);
 
 const char *genie_strerror(int status);
 const char *genie_last_hip_error(void);

@@ -1,47 +1,72 @@
 #!/usr/bin/env python3
-"""Digest a rocprofv3 output directory (kernel-trace --stats pass + the two --pmc passes that
-the round's gpurun command produced) into profiles/<tag>_*.  Usage:
-    python profiles/summarize.py gpurun_out/prof_r1a r1a "config1:lut:1000000"
-Traffic follows MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE come from separate
---pmc passes, are in KiB, and on gfx950 FETCH_SIZE is doubled (it tallies 128-B requests as
-64 B for wide coalesced reads; our access mix is narrower, so the doubled figure is an upper
-bound -- both are recorded)."""
+"""Digest one tools/profile_round.sh output directory (a kernel-trace --stats pass + one rocprofv3 --pmc pass per
+counter set) into
+    <dir>/summary.json                 per-kernel average duration and counters of this workload
+    profiles/<tag>_summary.json        the same, tracked
+    profiles/<tag>_kernel_stats.csv    rocprofv3's own --stats table
+    profiles/pmc_counters.json         merged: what bench.py reports as roofline.traffic / step / binding
+Usage:  python profiles/summarize.py gpurun_out/prof_<tag> <tag>
+
+HBM traffic follows MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE come from separate --pmc passes, are in
+KiB, and on gfx950 FETCH_SIZE counts half the bytes of a coalesced streaming read, so
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024           (an upper bound for our narrower access mix;
+    hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024            both are recorded)."""
 import collections
 import csv
+import glob
 import json
 import os
 import re
 import shutil
 import sys
 
-src, tag, key = sys.argv[1], sys.argv[2], sys.argv[3]
+src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-shutil.copy(os.path.join(src, "kt_kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_stats.csv"))
-pmc = {}
-for name, f in (("FETCH_SIZE", "pmc_fetch_counter_collection.csv"), ("WRITE_SIZE", "pmc_write_counter_collection.csv")):
-    agg = collections.defaultdict(list)
-    for row in csv.DictReader(open(os.path.join(src, f))):
-        if row["Counter_Name"] == name:
-            agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-    for k, v in agg.items():
-        m = re.search(r"(match_stats\w*kernel<[^>]*>|traverse_kernel<[^>]*>|interval_kernel<[^>]*>|interval_kernel|compact_\w+|sa_interval_kernel|seed_lookup_kernel<\d>)", k)
-        if m:
-            pmc.setdefault(m.group(1), {})[name + "_KiB_per_launch"] = sum(v) / len(v)
-            pmc[m.group(1)]["launches"] = len(v)
-for k, d in pmc.items():
-    f, w = d.get("FETCH_SIZE_KiB_per_launch", 0.0), d.get("WRITE_SIZE_KiB_per_launch", 0.0)
-    d["hbm_bytes_per_launch_raw"] = (f + w) * 1024
-    d["hbm_bytes_per_launch_gfx950_corrected"] = (2 * f + w) * 1024
-stats = list(csv.DictReader(open(os.path.join(src, "kt_kernel_stats.csv"))))
-out = {"tag": tag, "workload": key, "kernel_stats": [
-    {"name": r["Name"][:110], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
-    for r in stats if "genie" in r["Name"]], "pmc": pmc}
-json.dump(out, open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
-# the value bench.py reports as roofline.traffic (dominant kernel, corrected bytes per launch)
-tpath = os.path.join(here, "pmc_traffic.json")
-traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-dom = [k for k in pmc if k.startswith("match_stats")]
-if dom:
-    traffic[key] = pmc[dom[0]]["hbm_bytes_per_launch_gfx950_corrected"]
-json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
-print(json.dumps(out, indent=1))
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("genie::(anonymous namespace)::", "")
+    depth, out = 0, []
+    for ch in name:                       # cut the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)
+
+
+bench = json.loads(open(os.path.join(src, "kt_bench.json")).read().strip().splitlines()[-1])
+key = bench["config"]["counters_key"]
+kernels = collections.defaultdict(dict)
+for r in csv.DictReader(open(os.path.join(src, "kt_kernel_stats.csv"))):
+    if "genie" in r["Name"]:
+        kernels[short(r["Name"])].update(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"]))
+for f in sorted(glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "genie" in r["Kernel_Name"]:
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in agg.items():
+        for c, v in d.items():
+            kernels[k][c] = sum(v) / len(v)                   # average per launch
+for k, d in kernels.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_bytes"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+        d["hbm_bytes_raw"] = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+out = {"tag": tag, "key": key, "workload": bench["config"]["workload"], "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "n_gpus")},
+       "xcds": 8, "simds": 1024, "kernels": kernels}
+json.dump(out, open(os.path.join(src, "summary.json"), "w"), indent=1, sort_keys=True)
+if os.path.isdir(here) and os.access(here, os.W_OK):
+    shutil.copy(os.path.join(src, "kt_kernel_stats.csv"), os.path.join(here, f"{tag}_kernel_stats.csv"))
+    json.dump(out, open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1, sort_keys=True)
+    path = os.path.join(here, "pmc_counters.json")
+    merged = json.load(open(path)) if os.path.exists(path) else {}
+    merged[key] = {"tag": tag, "xcds": 8, "simds": 1024, "kernels": kernels}
+    json.dump(merged, open(path, "w"), indent=1, sort_keys=True)
+for k, d in sorted(kernels.items(), key=lambda kv: -kv[1].get("avg_ns", 0)):
+    print(f"{k[:60]:60s} {d.get('avg_ns', 0) / 1e3:9.1f} us  hbm {d.get('hbm_bytes', 0) / 1e6:8.1f} MB  valu {d.get('SQ_INSTS_VALU', 0) / 1e6:7.1f} M  "
+          f"l2rd {d.get('TCP_TCC_READ_REQ_sum', 0) / 1e6:7.1f} M")

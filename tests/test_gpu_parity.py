@@ -700,24 +700,14 @@ def test_one_megabase_reference(pkg, oracle_mod):
         assert tuple(got[i]) == o.back_prop(pats[i, :lens[i]]), i
 
 
-# ------------------------------------------------------------------ full-size properties (config 2/3 shape)
-def test_full_size_properties(pkg, oracle_mod):
-    """1M x 150 bp reads on the 100 kb reference (BASELINE config 1/2 shape).  Size-independent
-    properties: the three traversals agree bit for bit, repeated runs are identical, covers are
-    monotone, every emitted substring re-searches to its own interval with the batched exact-match
-    kernel -- plus a 60 000-read slice compared row by row with the CPU oracle.
-    (This test is the guard that caught wrong intervals from an earlier kernel structure that
-    only misbehaved at full occupancy; keep it at full size.)"""
+# ------------------------------------------------------------------ full-size properties
+def _full_size_properties(ix, o, rd_np, L, n_ref):
+    """Size-independent properties of a full-size batch: the three traversals agree bit for bit, repeated runs are
+    identical, covers are monotone, every emitted substring re-searches to its own interval with the batched
+    exact-match kernel (a different kernel) -- plus three 20 000-read slices (start, middle, end of the batch)
+    compared row by row with the CPU oracle."""
     import torch
-    from genie_smem_amd import synth as B
-    d, _ = G.load("syn100k_K15")
-    ix = _index_for(pkg, "syn100k_K15", "rmi")
-    n_reads = 1_000_000
-    import os
-    seed = int(os.environ.get("GENIE_TEST_SEED", "1002"))            # vary to soak-test the full-occupancy guard
-    rd_np = B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, seed)
-    if seed % 2:                                                     # odd seeds: a third of the batch uniform-random
-        rd_np[::3] = B.reads_random((n_reads + 2) // 3, 150, seed + 1)
+    n_reads = len(rd_np)
     rd = torch.as_tensor(rd_np).cuda()
     res = {}
     for rep in range(2):
@@ -728,33 +718,104 @@ def test_full_size_properties(pkg, oracle_mod):
                 res[algo] = (offsets, smems)
             else:
                 assert torch.equal(res[algo][0], offsets) and torch.equal(res[algo][1], smems), algo   # deterministic
-    for algo in ("bwa", "rmi"):
-        assert torch.equal(res[algo][0], res["lut"][0]) and torch.equal(res[algo][1], res["lut"][1]), algo
+                res[algo] = (offsets, smems) if algo == "lut" else None
+            del offsets, smems
+        if rep == 0:
+            for algo in ("bwa", "rmi"):
+                assert torch.equal(res[algo][0], res["lut"][0]) and torch.equal(res[algo][1], res["lut"][1]), algo
     offsets, smems = res["lut"]
+    del res
     start, end, lo, hi = smems[:, 0], smems[:, 1], smems[:, 2], smems[:, 3]
-    assert bool(((start >= 0) & (start < end) & (end <= 150) & (lo >= 0) & (lo <= hi) & (hi <= ix.n)).all())
+    assert bool(((start >= 0) & (start < end) & (end <= L) & (lo >= 0) & (lo <= hi) & (hi <= n_ref)).all())
     # last SMEM of each read ends at the read end; ends strictly increase inside a read
     last = offsets[1:] - 1
-    assert bool((end[last] == 150).all())
+    assert bool((end[last] == L).all())
     same_read = torch.ones(len(end) - 1, dtype=torch.bool, device=end.device)
     same_read[(offsets[1:-1] - 1)] = False
     assert bool((end[1:][same_read] > end[:-1][same_read]).all())
-    # re-search emitted substrings with the batched exact-match kernel (a different kernel)
-    sel = torch.randperm(len(start), device=start.device)[:400000]
+    del same_read, last
+    # re-search emitted substrings with the batched exact-match kernel
+    sel = torch.randint(0, len(start), (400_000,), device=start.device)
     read_of = torch.searchsorted(offsets, sel, right=True) - 1
     lens = (end[sel] - start[sel]).to(torch.int32)
-    idx = start[sel].long()[:, None] + torch.arange(150, device=rd.device)[None, :]
-    pats = torch.gather(rd[read_of], 1, idx.clamp(max=149))
+    idx = start[sel].long()[:, None] + torch.arange(L, device=rd.device)[None, :]
+    pats = torch.gather(rd[read_of], 1, idx.clamp(max=L - 1))
     got = ix.sa_interval(pats, lens)
     assert torch.equal(got[:, 0], lo[sel]) and torch.equal(got[:, 1], hi[sel])
     # oracle, row by row, on slices taken from the start, the middle and the end of the batch
-    o = oracle_mod.Oracle(d["ref_codes"], int(d["K"]))
     off = offsets.cpu().numpy()
-    sm = smems.cpu().numpy()
-    for a in (0, 480_000, 980_000):
+    for a in (0, (n_reads // 2) // 20_000 * 20_000, n_reads - 20_000):
         b = a + 20_000
+        sm = smems[off[a]:off[b]].cpu().numpy()
         counts, want = o.find_smems_batch("lut", rd_np[a:b], nthreads=16)
         assert (np.diff(off[a:b + 1]) == counts).all()
         rows = np.repeat(np.arange(b - a), counts)
         tpos = np.arange(len(rows)) - np.repeat(off[a:b] - off[a], counts)
-        assert (want[rows, tpos] == sm[off[a]:off[b]]).all()
+        assert (want[rows, tpos] == sm).all()
+
+
+def test_full_size_properties(pkg, oracle_mod):
+    """1M x 150 bp reads on the 100 kb reference (BASELINE config 1/2 shape): see _full_size_properties.
+    (This test is the guard that caught wrong intervals from an earlier kernel structure that only misbehaved
+    at full occupancy; keep it at full size.)"""
+    import os
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ix = _index_for(pkg, "syn100k_K15", "rmi")
+    n_reads = 1_000_000
+    seed = int(os.environ.get("GENIE_TEST_SEED", "1002"))            # vary to soak-test the full-occupancy guard
+    rd_np = B.reads_from_ref_fast(d["ref_codes"], n_reads, 150, seed)
+    if seed % 2:                                                     # odd seeds: a third of the batch uniform-random
+        rd_np[::3] = B.reads_random((n_reads + 2) // 3, 150, seed + 1)
+    _full_size_properties(ix, oracle_mod.Oracle(d["ref_codes"], int(d["K"])), rd_np, 150, ix.n)
+
+
+def _index_1mb(pkg, oracle_mod):
+    from genie_smem_amd import synth as B
+    ref = B.synth_ref(1_000_000, 1_000_000)
+    m = pkg.ExactMatch("REF_1M.fa")
+    m.set_reference(G.codes_to_str(ref))
+    r = pkg.RMI_LUT([1000], 15, "REF_1M.fa", matcher=m)
+    r.train_RMI()
+    o = oracle_mod.Oracle(ref, 15)
+    coefs, icpts = r.rmi.coefficients()
+    o.set_rmi([1000], coefs, icpts)
+    return ref, r._index(), o
+
+
+def test_full_size_properties_one_megabase(pkg, oracle_mod):
+    """BASELINE configs[3] at full size: REF_1M, natively trained RMI [1000], 10 M x 150 bp from-ref reads (every
+    100th read uniform-random): the same properties as on the 100 kb reference -- the larger, cache-missing index
+    at full occupancy."""
+    from genie_smem_amd import synth as B
+    ref, ix, o = _index_1mb(pkg, oracle_mod)
+    n_reads = 10_000_000
+    rd_np = np.concatenate([B.reads_from_ref_fast(ref, 2_500_000, 150, 1004 + 31 * c) for c in range(4)])
+    rd_np[::100] = B.reads_random(n_reads // 100, 150, 1006)
+    _full_size_properties(ix, o, rd_np, 150, ix.n)
+
+
+def test_sharded_run_equals_unsharded(pkg, oracle_mod):
+    """BASELINE configs[4] cuts ONE batch into contiguous shards (parallel.shard_bounds), one per GPU, with rank-local
+    outputs.  On one GPU: run W in {2, 4, 8} shards one after the other and check that the concatenated offsets /
+    rows / status equal the unsharded call bit for bit (reads are independent units: SMEM/SMEM.py:20,206,456)."""
+    import torch
+    from genie_smem_amd import parallel, synth as B
+    ref, ix, _ = _index_1mb(pkg, oracle_mod)
+    n_reads = 200_003                                                # not a multiple of any W
+    rd = torch.as_tensor(B.reads_from_ref_fast(ref, n_reads, 150, 1005)).cuda()
+    rd[7, 3] = 9                                                     # a flagged read must stay flagged in its shard
+    for algo in ("rmi", "lut"):
+        off0, rows0, st0 = ix.find_smems(algo, rd)
+        assert int(st0[7].item()) != 0 and int(st0.abs().sum().item()) == int(st0[7].abs().item())
+        for W in (2, 4, 8):
+            offs, rows, sts, base = [], [], [], 0
+            for rank in range(W):
+                lo, hi = parallel.shard_bounds(n_reads, rank, W)
+                o_, r_, s_ = ix.find_smems(algo, rd[lo:hi])
+                offs.append(o_[:-1] + base)
+                base += int(o_[-1].item())
+                rows.append(r_)
+                sts.append(s_)
+            offs.append(torch.tensor([base], dtype=off0.dtype, device=off0.device))
+            assert torch.equal(torch.cat(offs), off0) and torch.equal(torch.cat(rows), rows0) and torch.equal(torch.cat(sts), st0), (algo, W)
