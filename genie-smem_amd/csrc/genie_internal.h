@@ -202,6 +202,7 @@ struct genie_index {
     int32_t opt_legacy_search = 0;   // GENIE_OPT_LEGACY_SEARCH
     int32_t opt_group_positions = 0; // GENIE_OPT_GROUP_POSITIONS (0 = default)
     int32_t opt_search_only = 0;     // GENIE_OPT_SEARCH_ONLY
+    int32_t opt_search_blocks_per_cu = 0;   // GENIE_OPT_SEARCH_BLOCKS_PER_CU (0 = as many as fit)
     void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel
     void *ev_search_end = nullptr;
 };

@@ -697,6 +697,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
         g->leaf_in_lds = 0;
         g->block = wpb * kWave;
         int bpc = std::min(lds_cap / g->lds, 32 / wpb);
+        if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
         if (bpc < 1) bpc = 1;
         long long gr = (long long)cus * bpc;
         const long long need2 = (N + (long long)wpb * grp - 1) / ((long long)wpb * grp);
@@ -850,7 +851,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
-                           g.grp, g.max_len, g.recip, (long long)sizeof(MatchRec) << (2 * ix->dev.P2));
+                           g.grp, g.max_len, (long long)sizeof(MatchRec) << (2 * ix->dev.P2));
     } else if (WIDE && g.win) {
         auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));

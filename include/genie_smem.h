@@ -225,7 +225,7 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  * way; on MI355X the LDS-staged P-mer directory already narrows a position to a handful of rows,
  * so the extra probe only costs time (measured: DESIGN.md) and is off by default. */
 enum { GENIE_OPT_LUT_PROBE = 1, GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_LEGACY_SEARCH = 3, GENIE_OPT_GROUP_POSITIONS = 4,
-       GENIE_OPT_SEARCH_ONLY = 5 };
+       GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6 };
 /* GENIE_OPT_SEARCH_ALL (default 0): the matching statistics fwd[] are non-decreasing along a read, so by
  * default reads are searched at every 4th position first and only the gaps whose two ends disagree are
  * searched inside (identical results; 1.6x to 3.7x faster on reads that match the reference end to end,

@@ -12,6 +12,8 @@ def main():
     ref = synth.synth_ref(n, n)
     ix = g.GenieIndex.build(ref, K).to("cuda")
     lib = g._native.lib()
+    if os.environ.get("BPC"):
+        ix.set_option(6, int(os.environ["BPC"]))
     reads = torch.as_tensor(synth.reads_from_ref_fast(ref, N, L, 1002)).cuda()
     def bufs(nr):
         ws_b = int(lib.genie_find_smems_workspace_bytes(nr, L))
