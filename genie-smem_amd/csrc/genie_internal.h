@@ -38,19 +38,27 @@ constexpr int32_t kFlagDir16 = 1;
 //   meta byte 1  lmask  0x1F when the P2-mer occurs and the entry is not slow, else 0:
 //                       longest match >= base + (lcp & lmask)
 //   meta byte 2  flags  kMatchSlow: more than kMatchKeys suffixes, or one of them has fewer than
-//                       P2 + 16 bases (its key is zero padded) -- the entry only proves `base`
+//                       P2 + 16 bases (its key is zero padded) -- the entry alone only proves `base`;
+//                       kMatchMore (with kMatchSlow): kMatchKeys + 1 .. kMatchChainRows suffixes, none cut
+//                       short: key[kMatchKeys - 1] is the index (in 32-byte entries from the table start) of
+//                       overflow entries holding keys kMatchKeys - 1, kMatchKeys, ... eight per entry
 //   meta byte 3  rows   min(number of suffixes, 255)
-//   key[i]              the 16 bases that FOLLOW the first P2 bases of the i-th of them (suffix-array order, so
-//                       ascending), packed like the reference (base j in bits [30-2j, 31-2j]); unused slots
-//                       repeat key[0].  meta + key[0..2] are the first 16 bytes: most positions need no more
-//                       (three or fewer suffixes, or a query key that does not exceed key[2]).
+//   lb                  suffix-array row of the first of them (rows of one P2-mer are contiguous)
+//   key[i]              the 16 bases that FOLLOW the first P2 bases of suffix-array row lb + i (so the keys
+//                       ascend), packed like the reference (base j in bits [30-2j, 31-2j]); unused slots
+//                       repeat key[0].  meta, lb, key[0..1] are the first 16 bytes: most positions need no
+//                       more (two or fewer suffixes, or a query key that does not exceed key[1]).
 // The longest match of a query position is  min(base + max_i lcp(query key, key[i]), bases left)  unless
 // the entry is slow or a key agrees in all 16 bases with more of the read left: then the suffix-array
-// rows whose keys agree (or, for a slow entry, a search of all its rows) decide.
-constexpr int kMatchKeys = 7;
+// rows lb + i whose keys agree (or, for a slow entry, a search of all its rows) decide.  The rows that hold
+// a pattern of P2 .. P2 + 16 bases are lb + i for the keys that agree with it that far (interval search).
+constexpr int kMatchKeys = 6;
 constexpr uint32_t kMatchSlow = 1u << 16;
+constexpr uint32_t kMatchMore = 1u << 17;
+constexpr int kMatchChainRows = kMatchKeys - 1 + 8 * 3;      // longest chain: three overflow entries
 struct MatchRec {
     uint32_t meta;
+    uint32_t lb;
     uint32_t key[kMatchKeys];
 };
 static_assert(sizeof(MatchRec) == 32, "MatchRec must be one 32-byte fetch");
@@ -135,7 +143,8 @@ struct DevIndex {
     const RmiModel *rmi;
     const HeadRec *dir2;   // second-level range table (global, L2-resident), or null
     const int32_t *rmi_err; // per-leaf error bounds of a natively trained RMI, or null
-    const MatchRec *mtab;  // match table, 4^P2 entries
+    const MatchRec *mtab;  // match table, 4^P2 entries + overflow entries
+    int32_t mtab_entries;
     int32_t flags;
     int32_t n;
     int32_t K;
@@ -202,6 +211,7 @@ struct genie_index {
     int32_t opt_legacy_search = 0;   // GENIE_OPT_LEGACY_SEARCH
     int32_t opt_group_positions = 0; // GENIE_OPT_GROUP_POSITIONS (0 = default)
     int32_t opt_search_only = 0;     // GENIE_OPT_SEARCH_ONLY
+    int32_t opt_debug = 0;           // experiments: stages of the search kernel switched off (results invalid)
     int32_t opt_search_blocks_per_cu = 0;   // GENIE_OPT_SEARCH_BLOCKS_PER_CU (0 = as many as fit)
     void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel
     void *ev_search_end = nullptr;

@@ -184,8 +184,9 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
             h->P2 = P2;
             const int64_t nb2 = (int64_t)1 << (2 * P2);
             h->dir2.assign((size_t)nb2, HeadRec{0, 0, 0});
-            h->mtab.assign((size_t)nb2, MatchRec{0, {0, 0, 0, 0, 0, 0, 0}});
+            h->mtab.assign((size_t)nb2, MatchRec{0, 0, {0, 0, 0, 0, 0, 0}});
             std::vector<uint32_t> cnt((size_t)nb2, 0);
+            std::vector<uint8_t> cut((size_t)nb2, 0);                   // a suffix of the entry has fewer than P2 + 16 bases
             for (int64_t r = 0; r < rows; r++) {
                 const int64_t s = h->sa0[(size_t)r];
                 if (n - s < P2) continue;
@@ -195,21 +196,43 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                     e.lb = (uint32_t)r;
                     e.key = h->sarec[(size_t)r].key;
                     e.meta = (n - s < P + 32) ? kHeadShort : 0;
+                    h->mtab[(size_t)c].lb = (uint32_t)r;
                 }
                 e.meta++;
-                MatchRec &m = h->mtab[(size_t)c];
-                const uint32_t k = cnt[(size_t)c]++;
-                if (k < (uint32_t)kMatchKeys) {
-                    uint32_t key = 0;
-                    for (int j = 0; j < 16; j++) {
-                        const int64_t p = s + P2 + j;
-                        key |= (p < n ? (uint32_t)codes[p] : 0u) << (30 - 2 * j);
-                    }
-                    m.key[k] = key;
-                } else {
-                    m.meta |= kMatchSlow;
+                cnt[(size_t)c]++;
+                if (n - s < P2 + 16) cut[(size_t)c] = 1;
+            }
+            // keys: up to kMatchKeys in the entry itself; kMatchKeys+1 .. kMatchChainRows rows: kMatchKeys-1 in the
+            // entry, its last slot = index of the overflow entries (8 keys each) appended behind the table
+            for (int64_t r = 0; r < rows; r++) {
+                const int64_t s = h->sa0[(size_t)r];
+                if (n - s < P2) continue;
+                const uint64_t c = code_at64(codes, s, P2);
+                const uint32_t rows_c = cnt[(size_t)c], k = (uint32_t)r - h->mtab[(size_t)c].lb;
+                uint32_t key = 0;
+                for (int j = 0; j < 16; j++) {
+                    const int64_t p = s + P2 + j;
+                    key |= (p < n ? (uint32_t)codes[p] : 0u) << (30 - 2 * j);
                 }
-                if (n - s < P2 + 16) m.meta |= kMatchSlow;
+                const bool chain = !cut[(size_t)c] && rows_c > (uint32_t)kMatchKeys && rows_c <= (uint32_t)kMatchChainRows;
+                if (!chain) {
+                    if (k < (uint32_t)kMatchKeys) h->mtab[(size_t)c].key[k] = key;
+                    continue;
+                }
+                if (k == 0) {                                             // reserve the overflow entries, filled with key 0
+                    const uint32_t extra = (rows_c - (kMatchKeys - 1) + 7) / 8;
+                    h->mtab[(size_t)c].key[kMatchKeys - 1] = (uint32_t)h->mtab.size();
+                    MatchRec fill;
+                    uint32_t *fw = reinterpret_cast<uint32_t *>(&fill);
+                    for (int j = 0; j < 8; j++) fw[j] = key;
+                    for (uint32_t x = 0; x < extra; x++) h->mtab.push_back(fill);
+                }
+                if (k < (uint32_t)kMatchKeys - 1) {
+                    h->mtab[(size_t)c].key[k] = key;
+                } else {
+                    const uint32_t o = k - (kMatchKeys - 1);
+                    reinterpret_cast<uint32_t *>(&h->mtab[(size_t)h->mtab[(size_t)c].key[kMatchKeys - 1] + o / 8])[o % 8] = key;
+                }
             }
             // which t-mers (t < P2) occur anywhere in the reference, its last bases included
             std::vector<std::vector<uint8_t>> occ((size_t)P2);
@@ -231,8 +254,10 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                     while (t >= 1 && !occ[(size_t)t][(size_t)((uint64_t)c >> (2 * (P2 - t)))]) t--;
                     m.meta = (uint32_t)t;                                // lmask = 0, flags = 0, rows = 0
                 } else {
+                    const bool chain = !cut[(size_t)c] && k > (uint32_t)kMatchKeys && k <= (uint32_t)kMatchChainRows;
                     for (uint32_t i = k; i < (uint32_t)kMatchKeys; i++) m.key[i] = m.key[0];
-                    const uint32_t slow = m.meta & kMatchSlow;                 // a slow entry proves P2 bases, no more
+                    // an entry that cannot decide alone proves P2 bases, no more: more rows than keys, or a cut-short suffix
+                    const uint32_t slow = (k > (uint32_t)kMatchKeys || cut[(size_t)c]) ? kMatchSlow | (chain ? kMatchMore : 0u) : 0u;
                     m.meta = slow | (uint32_t)P2 | (slow ? 0u : 0x1Fu << 8) | ((k < 255 ? k : 255u) << 24);
                 }
             }
@@ -496,7 +521,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     if (hdr.K < 0 || hdr.K > GENIE_MAX_K) return GENIE_E_BAD_BLOB;
     if (hdr.dir_entries != ((int64_t)1 << (2 * hdr.P)) + 1) return GENIE_E_BAD_BLOB;
     if (hdr.P2 <= hdr.P || hdr.P2 > 12 || hdr.dir2_entries != ((int64_t)1 << (2 * hdr.P2)) ||
-        hdr.mtab_entries != hdr.dir2_entries)
+        hdr.mtab_entries < hdr.dir2_entries || hdr.mtab_entries > hdr.dir2_entries + hdr.n || hdr.mtab_entries > (1 << 26))
         return GENIE_E_BAD_BLOB;
     if (hdr.ref_recs < (hdr.n + 31) / 32 + 3) return GENIE_E_BAD_BLOB;
     // every section inside the image (a truncated or corrupt image must not become a wild device pointer)
@@ -535,6 +560,7 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->rmi = (const RmiModel *)(p + hdr.off_rmi);
     out->dir2 = (const HeadRec *)(p + hdr.off_dir2);
     out->mtab = (const MatchRec *)(p + hdr.off_mtab);
+    out->mtab_entries = (int32_t)hdr.mtab_entries;
     out->P2 = hdr.P2;
     out->flags = hdr.flags;
     out->rmi_err = hdr.rmi_err_entries > 0 ? (const int32_t *)(p + hdr.off_rmi_err) : nullptr;

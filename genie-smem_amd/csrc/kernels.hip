@@ -851,7 +851,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
-                           g.grp, g.max_len, (long long)sizeof(MatchRec) << (2 * ix->dev.P2));
+                           g.grp, g.max_len, (long long)sizeof(MatchRec) * ix->dev.mtab_entries, ix->opt_debug);
     } else if (WIDE && g.win) {
         auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));

@@ -314,13 +314,14 @@ def test_second_level_range_table(pkg):
 
 def _match_table(img, h):
     return np.frombuffer(bytes(img[h["off_mtab"]:h["off_mtab"] + 32 * h["mtab_entries"]]),
-                         np.dtype([("meta", "<u4"), ("key", "<u4", (7,))]))
+                         np.dtype([("meta", "<u4"), ("lb", "<u4"), ("key", "<u4", (6,))]))
 
 
 @pytest.mark.parametrize("case", ["syn10k", "tail_A", "tiny", "repeat"])
 def test_match_table_against_brute_force(pkg, case):
-    """MatchRec per P2-mer (genie_internal.h): base / lmask / slow flag / row count and the 16-base
-    continuations of its suffixes, against a direct enumeration of the reference's substrings."""
+    """MatchRec per P2-mer (genie_internal.h): base / lmask / flags / row count / first row and the 16-base
+    continuations of its suffixes -- in the entry, or chained through overflow entries -- against a direct
+    enumeration of the reference's substrings."""
     rng = np.random.default_rng(77)
     if case == "syn10k":
         ref = rng.integers(0, 4, 10_000).astype(np.uint8)
@@ -328,17 +329,19 @@ def test_match_table_against_brute_force(pkg, case):
         ref = np.concatenate([rng.integers(0, 4, 3000), np.zeros(40, np.int64)]).astype(np.uint8)
     elif case == "tiny":
         ref = rng.integers(0, 4, 13).astype(np.uint8)
-    else:                                        # a tandem repeat: one P2-mer with many suffixes
-        ref = np.concatenate([np.tile([0, 1, 2, 3, 3, 1], 60), rng.integers(0, 4, 2000)]).astype(np.uint8)
+    else:                                        # tandem repeats: P2-mers with 10 and with 60 suffixes
+        ref = np.concatenate([np.tile([0, 1, 2, 3, 3, 1], 60), rng.integers(0, 4, 1000), np.tile([2, 2, 0, 1, 3, 0, 1, 1, 2, 3], 11),
+                              rng.integers(0, 4, 1000)]).astype(np.uint8)
     n = len(ref)
     ix = pkg.GenieIndex.build(ref, 6)
     img = ix.serialize().numpy()
     h = _parse(img)
     P2 = h["P2"]
-    assert h["mtab_entries"] == 4 ** P2 == h["dir2_entries"]
+    assert h["dir2_entries"] == 4 ** P2 <= h["mtab_entries"]
     mt = _match_table(img, h)
+    raw = np.frombuffer(bytes(img[h["off_mtab"]:h["off_mtab"] + 32 * h["mtab_entries"]]), "<u4").reshape(-1, 8)
     base, lmask = mt["meta"] & 0xFF, (mt["meta"] >> 8) & 0xFF
-    slow, rows = (mt["meta"] >> 16) & 1, mt["meta"] >> 24
+    slow, more, rows = (mt["meta"] >> 16) & 1, (mt["meta"] >> 17) & 1, mt["meta"] >> 24
     s = "".join("ACGT"[c] for c in ref)
     occ = [set()] + [{s[i:i + t] for i in range(n - t + 1)} for t in range(1, P2 + 1)]
     sa0 = ix.suffix_array().astype(np.int64) - 1
@@ -348,24 +351,39 @@ def test_match_table_against_brute_force(pkg, case):
             by_code.setdefault(s[st:st + P2], []).append(int(st))
             first_row.setdefault(s[st:st + P2], row)
     code_of = lambda t: int("".join(str("ACGT".index(c)) for c in t), 4)        # noqa: E731
-    seen = 0
+
+    def key_of(st):
+        k = 0
+        for j in range(16):
+            k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (30 - 2 * j)
+        return k
+
+    seen, used, chained = 0, 4 ** P2, 0
     for mer, starts in by_code.items():
         c = code_of(mer)
         seen += 1
         cut = any(n - st < P2 + 16 for st in starts)
-        assert base[c] == P2 and rows[c] == min(len(starts), 255)
-        assert slow[c] == int(len(starts) > 7 or cut)
+        chain = not cut and 6 < len(starts) <= 29
+        assert base[c] == P2 and rows[c] == min(len(starts), 255) and mt["lb"][c] == first_row[mer]
+        assert slow[c] == int(len(starts) > 6 or cut) and more[c] == int(chain)
         assert lmask[c] == (0 if slow[c] else 0x1F)
-        keys = []
-        for st in starts[:7]:
-            k = 0
-            for j in range(16):
-                k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (30 - 2 * j)
-            keys.append(k)
-        keys += [keys[0]] * (7 - len(keys))
-        assert slow[c] or keys[:len(starts)] == sorted(keys[:len(starts)])      # ascending: suffix-array order
-        assert mt["key"][c].tolist() == keys, mer
-    absent = np.nonzero(base < P2)[0]
+        keys = [key_of(st) for st in starts]
+        if chain:
+            chained += 1
+            assert mt["key"][c][:5].tolist() == keys[:5]
+            o = int(mt["key"][c][5])
+            extra = (len(starts) - 5 + 7) // 8
+            assert used <= o and o + extra <= h["mtab_entries"]
+            got = raw[o:o + extra].reshape(-1).tolist()
+            assert got[:len(keys) - 5] == keys[5:] and all(g == keys[0] for g in got[len(keys) - 5:]), mer
+            assert keys == sorted(keys)
+        else:
+            k6 = keys[:6] + [keys[0]] * max(0, 6 - len(keys))
+            assert mt["key"][c].tolist() == k6, mer
+            assert slow[c] or keys == sorted(keys)      # ascending: suffix-array order
+    if case == "repeat":
+        assert chained >= 5 and (slow & (1 - more) & (rows > 29)).any()
+    absent = np.nonzero(base[:4 ** P2] < P2)[0]
     assert len(absent) == 4 ** P2 - seen
     for c in (absent if len(absent) < 3000 else rng.choice(absent, 3000, replace=False)):
         mer = "".join("ACGT"[(int(c) >> (2 * (P2 - 1 - j))) & 3] for j in range(P2))
@@ -418,5 +436,5 @@ def test_corrupt_image_is_rejected(pkg):
                 dict(lut_slots=0), dict(lut_slots=h["lut_keys"]), dict(lut_slots=1 << 40), dict(n=h["n"] + 10 ** 7),
                 dict(K=17), dict(K=-1), dict(nlev=5), dict(nlev=-1), dict(rmi_models=h["rmi_models"] + 1),
                 dict(rmi_err_entries=h["rmi_err_entries"] + 1), dict(P2=h["P"]), dict(P2=13),
-                dict(mtab_entries=h["mtab_entries"] - 1), dict(dir2_entries=4), dict(ref_recs=1), dict(version=6)):
+                dict(mtab_entries=h["dir2_entries"] - 1), dict(mtab_entries=1 << 27), dict(dir2_entries=4), dict(ref_recs=1), dict(version=6)):
         assert corrupt(**bad) == -8, bad
