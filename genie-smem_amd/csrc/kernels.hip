@@ -706,6 +706,24 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len
         g->grid = (int)gr;
         return GENIE_OK;
     }
+    if (g->wide && !ix->opt_legacy_search) {
+        // long reads: one wave per read, eight waves per block
+        const int wpb = 8;
+        g->mt = 1;
+        g->grp = 1;
+        g->lds = wpb * mt_long_wave_bytes(max_len, g->qp_recs);
+        g->leaf_in_lds = 0;
+        g->block = wpb * kWave;
+        int bpc = std::min(lds_cap / g->lds, 32 / wpb);
+        if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
+        if (bpc < 1) bpc = 1;
+        long long gr = (long long)cus * bpc;
+        const long long need2 = (N + wpb - 1) / wpb;
+        if (gr > need2) gr = need2;
+        if (gr < 1) gr = 1;
+        g->grid = (int)gr;
+        return GENIE_OK;
+    }
     if (g->wide && (d.flags & kFlagDir16) && !ix->opt_search_all) {
         // sampled search for long reads: one wave per read, windows of 704 positions
         const int win = 704;
@@ -852,6 +870,12 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
                            g.grp, g.max_len, (long long)sizeof(MatchRec) * ix->dev.mtab_entries, ix->opt_debug);
+    } else if (WIDE && g.mt) {
+        auto km = match_table_long_kernel;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
+                           g.max_len, (long long)sizeof(MatchRec) * ix->dev.mtab_entries);
     } else if (WIDE && g.win) {
         auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
@@ -964,7 +988,7 @@ int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, cha
     int rc = plan_find_smems(ix, mode, max_len, true, 1ll << 40, &g);
     if (rc) return rc;
     char tmp[160];
-    if (g.mt) snprintf(tmp, sizeof tmp, "match_table_kernel");
+    if (g.mt) snprintf(tmp, sizeof tmp, g.wide ? "match_table_long_kernel" : "match_table_kernel");
     else if (g.win) snprintf(tmp, sizeof tmp, "match_stats_sampled_long_kernel<%d, %s>", mode, ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false");
     else if (g.sampled) snprintf(tmp, sizeof tmp, "match_stats_sampled_kernel<%d, %s, %d>", mode, ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false", g.grp == 5 ? 5 : 0);
     else snprintf(tmp, sizeof tmp, "match_stats_kernel<%d, %d, %s, %s, %s>", mode, g.ns, g.wide ? "true" : "false", g.pair ? "true" : "false",
