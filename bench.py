@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
-    ap.add_argument("--legacy-search", action="store_true", help="GENIE_OPT_LEGACY_SEARCH: the suffix-array search kernels (A/B runs)")
+    ap.add_argument("--search-all", action="store_true", help="GENIE_OPT_SEARCH_ALL: look up every position, no sampling (A/B runs)")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -174,8 +174,8 @@ def main():
     mode = args.mode or cfg["mode"]
     if mode != cfg["mode"]:
         offcfg.append(f"mode={mode}")
-    if args.legacy_search:
-        offcfg.append("legacy-search")
+    if args.search_all:
+        offcfg.append("search-all")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,8 +198,8 @@ def main():
     if world > 1:
         ix = parallel.broadcast_index(ix, src=0, device=device)
     t_build = time.perf_counter() - t_build
-    if args.legacy_search:
-        ix.set_option(g._native.OPT_LEGACY_SEARCH, 1)
+    if args.search_all:
+        ix.set_option(g._native.OPT_SEARCH_ALL, 1)
 
     # ---- this rank's batch.  weak: the config's shape on every rank (seed + rank); strong: this rank's
     # contiguous shard of ONE batch (the shard is generated with the shard's own seed: shard s of W is the

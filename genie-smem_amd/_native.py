@@ -20,9 +20,10 @@ MAX_K = 16
 MAX_READ_LEN = 8192
 MODE_BWA, MODE_LUT, MODE_RMI = 0, 1, 2
 MODES = {"bwa": MODE_BWA, "lut": MODE_LUT, "rmi": MODE_RMI}
-OPT_LUT_PROBE = 1
 OPT_SEARCH_ALL = 2
-OPT_LEGACY_SEARCH = 3
+OPT_GROUP_POSITIONS = 4
+OPT_SEARCH_ONLY = 5
+OPT_SEARCH_BLOCKS_PER_CU = 6
 READ_OK, READ_BAD_BASE, READ_TOO_SHORT, READ_ABSENT_BASE, READ_OVERFLOW = 0, 1, 2, 3, 4
 
 # every symbol include/genie_smem.h declares (tests check the library exports all of them)

@@ -335,9 +335,7 @@ int genie_index_set_option(genie_index *ix, int32_t option, int32_t value)
 {
     if (!ix) return GENIE_E_INVALID;
     switch (option) {
-    case GENIE_OPT_LUT_PROBE: ix->opt_lut_probe = value != 0; return GENIE_OK;
     case GENIE_OPT_SEARCH_ALL: ix->opt_search_all = value != 0; return GENIE_OK;
-    case GENIE_OPT_LEGACY_SEARCH: ix->opt_legacy_search = value != 0; return GENIE_OK;
     case GENIE_OPT_GROUP_POSITIONS: ix->opt_group_positions = value > 0 ? value : 0; return GENIE_OK;
     case GENIE_OPT_SEARCH_ONLY: ix->opt_search_only = value != 0; return GENIE_OK;
     case 99: ix->opt_debug = ix->opt_search_only ? value : 0; return GENIE_OK;   // only with SEARCH_ONLY: never on a real run

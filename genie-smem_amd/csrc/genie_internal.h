@@ -206,9 +206,7 @@ struct genie_index {
     void *owned_blob = nullptr;      // hipMalloc'ed by genie_index_to_device
     int64_t blob_bytes = 0;
     int32_t num_cus = 0;
-    int32_t opt_lut_probe = 0;       // GENIE_OPT_LUT_PROBE
     int32_t opt_search_all = 0;      // GENIE_OPT_SEARCH_ALL
-    int32_t opt_legacy_search = 0;   // GENIE_OPT_LEGACY_SEARCH
     int32_t opt_group_positions = 0; // GENIE_OPT_GROUP_POSITIONS (0 = default)
     int32_t opt_search_only = 0;     // GENIE_OPT_SEARCH_ONLY
     int32_t opt_debug = 0;           // experiments: stages of the search kernel switched off (results invalid)

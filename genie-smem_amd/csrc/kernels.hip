@@ -3,8 +3,8 @@
 // Device building blocks (this file): packed 32-base windows, the P-mer prefix directory with its
 // exact tail corrections, suffix comparison on inline-key suffix-array records, interval search,
 // K-mer hash table probe, RMI prediction + last-mile search.
-// The read pipeline K_A (match statistics, one wave per read) -> K_B (traversal, one lane per read)
-// -> K_C (intervals, one lane per SMEM) lives in short_read_kernel.inc; the single-step kernels
+// The read pipeline K_A (match statistics, match_table_kernel.inc) -> K_B (traversal, one lane per read)
+// -> K_C (intervals, one lane per SMEM; short_read_kernel.inc); the single-step kernels
 // (batched exact match, seed lookup) and the offsets scan / compaction are below.
 // Pure integer / indexing work (one fp64 multiply-add per RMI level); no MFMA.
 //
@@ -89,14 +89,6 @@ struct QRecs {
 // suffix has fewer than P bases ("tails", P-1 of them plus the '$' row) need the two
 // corrections below; padtail[l] is the A-padded code of the tail of length l.
 //
-// The directory as 16-bit deltas against every 16th entry (36 KB instead of 64 KB of LDS):
-// dir[x] = coarse[x >> 4] + delta[x].  Usable when the image carries kFlagDir16.
-struct Dir16 {
-    const uint32_t *coarse;
-    const uint16_t *delta;
-    __device__ __forceinline__ uint32_t operator[](uint32_t x) const { return coarse[x >> 4] + delta[x]; }
-};
-
 // Rows with prefix `code` (m bases, 1 <= m <= P) are exactly [dir_lb, dir_ub).
 template <class D>
 __device__ __forceinline__ uint32_t dir_lb(const DevIndex &ix, const D dir, uint32_t code, int m)
@@ -217,12 +209,13 @@ __device__ __forceinline__ SaRec load_rec(const SaRec *sa, int row)
 __device__ __forceinline__ bool lut_probe(const DevIndex &ix, uint32_t code, int &lo, int &hi)
 {
     uint32_t p = (uint32_t)(((uint64_t)(code * 0x9E3779B1u) * (uint64_t)ix.lut_slots) >> 32);
-    for (;;) {
+    for (uint32_t tries = 0; tries < ix.lut_slots; tries++) {              // bounded: a corrupt table cannot spin a wave
         const int4 v = *reinterpret_cast<const int4 *>(ix.lut + p);
         if (v.y < 0) return false;
         if ((uint32_t)v.x == code) { lo = v.y; hi = v.z; return true; }
         p = p + 1 == ix.lut_slots ? 0 : p + 1;
     }
+    return false;
 }
 
 // RMI.predict for one key (SMEM/RMI.py:52-69): per level p = coef*x + intercept, rounded after
@@ -552,7 +545,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_scatter(const int32_t *__r
                                                               const int4 *__restrict__ slots, long long N, int cap,
                                                               const unsigned long long *__restrict__ block_sums,
                                                               long long *__restrict__ offsets, int4 *__restrict__ out,
-                                                              long long out_cap_rows, int *__restrict__ overflow)
+                                                              long long out_cap_rows)
 {
     __shared__ unsigned long long part[kScanBlock];
     const long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
@@ -573,7 +566,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_scatter(const int32_t *__r
         if (!out) {
             /* offsets only */
         } else if ((long long)(base + v) > out_cap_rows) {
-            *overflow = 1;
+            /* rows beyond the capacity are dropped: the caller compares offsets[N] with it */
         } else {
             for (unsigned int t = 0; t < (unsigned int)v; t++) out[base + t] = slots[i * (long long)cap + t];
         }
@@ -591,213 +584,64 @@ std::string g_err;
     } while (0)
 
 struct Geometry {
-    int grid, block, lds, leaf_in_lds;
-    int blocks_a;    // paired search: blocks [0, blocks_a) take role A, the rest role B
-    int sampled;     // sampled search (match_stats_sampled_kernel) with this work-list capacity, 0 = not used
-    int grp, sshift; // its reads per wave iteration and log2 of the sampling stride
-    int win;         // long reads: window of the sampled search (match_stats_sampled_long_kernel), 0 = not used
-    int mt;          // match-table kernel (reads of at most 255 bases): slow-list capacity, 0 = not used
-    uint32_t recip;  // its ceil(2^32 / max_len)
-    int pair;        // narrow fixed-length batch whose last slot holds <= 32 positions: two reads per wave iteration
-    int ns;          // position slots per chunk in K_A (1..4)
+    int grid, block, lds;
+    int grp;         // reads per wave iteration (long reads: 1)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
     int max_len;
     int fwd_stride;  // bytes per fwd[] row in the workspace
-    int qp_words;    // packed-read words per wave in LDS (incl. 2 zero words)
+    int fwd_lds;     // bytes per fwd[] row in K_B's LDS copy (narrow): an odd number of dwords
     int qp_recs;     // 16-byte packed-read records per read in the workspace
     int hm_words;    // hit-mask words per read + 1 (longest match)
     int kj_row;      // emitted-pair entries per read
 };
 
-inline int fwd_row_bytes(int max_len, bool wide)
-{
-    if (wide) return ((max_len * 2) + 15) & ~15;
-    int dw = (max_len + 3) / 4;
-    if (dw < 1) dw = 1;
-    if ((dw & 1) == 0) dw++;              // odd dword stride: conflict-free LDS rows in K_B
-    return dw * 4;
-}
-
 inline void shape_for(int max_len, Geometry *g)
 {
     g->max_len = max_len;
     g->wide = max_len > 255;
-    g->ns = g->wide ? 4 : std::max(1, (max_len + 63) / 64);
-    g->qp_words = g->wide ? (max_len + 31) / 32 + 2 : 2 * g->ns + 2;
-    g->qp_recs = g->qp_words - 2;
-    g->hm_words = (g->wide ? (max_len + 63) / 64 : g->ns) + 1;
-    g->fwd_stride = fwd_row_bytes(max_len, g->wide);
+    const int ns = g->wide ? (max_len + 63) / 64 : std::max(1, (max_len + 63) / 64);
+    g->qp_recs = g->wide ? (max_len + 31) / 32 : 2 * ns;
+    g->hm_words = ns + 1;
+    // rows are multiples of 16 bytes (K_A copies them out 16 bytes per lane); K_B's LDS rows are an odd number of
+    // dwords, so that lanes reading the same offset of their own rows hit distinct banks
+    g->fwd_stride = g->wide ? ((max_len * 2) + 15) & ~15 : std::max(16, (max_len + 15) & ~15);
+    int dw = std::max(1, (max_len + 3) / 4);
+    if ((dw & 1) == 0) dw++;
+    g->fwd_lds = dw * 4;
     g->kj_row = (std::max(max_len, 1) + 7) & ~7;
 }
 
-inline int sample_shift()
+int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
 {
-    const char *e = std::getenv("GENIE_SAMPLE_SHIFT");
-    const int v = e ? std::atoi(e) : 2;
-    return v >= 1 && v <= 4 ? v : 2;
-}
-
-int plan_find_smems(const genie_index *ix, int mode, int max_len, bool fixed_len, long long N, Geometry *g)
-{
-    const DevIndex &d = ix->dev;
-    const int dir_bytes = (d.dir_entries * 4 + 15) & ~15;
+    (void)mode;
     const int lds_cap = 160 * 1024;
     shape_for(max_len, g);
-    g->pair = !g->wide && fixed_len && max_len > 0 && max_len - 64 * (g->ns - 1) <= 32;
-    const int per_wave = g->qp_words * 8 * (g->pair ? 2 : 1);     // a wave packs one or two reads per iteration
-    // RMI leaf models: as many as fit beside the directory while TWO 16-wave blocks still share a CU's
-    // LDS (experts [1000] = 16 000 B fit but for ~30 models); the rest are read from global memory.
-    int leaf_bytes = 0;
-    if (mode == GENIE_MODE_RMI) {
-        const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
-        int room = lds_cap / 2 - dir_bytes - 16 * per_wave;
-        if (room < 0) room = 0;
-        leaf_bytes = std::min(cnt, room / 16) * 16;
-    }
-    int waves = (lds_cap - dir_bytes - leaf_bytes) / per_wave;
-    if (waves < 1) return GENIE_E_TOO_LONG;
-    if (waves > 16) waves = 16;
-    int w2 = 1;
-    while (w2 * 2 <= waves) w2 *= 2;
-    waves = w2;
-    const int lds = dir_bytes + leaf_bytes + waves * per_wave;
-    int blocks_per_cu = lds_cap / lds;
-    if (blocks_per_cu * waves > 32) blocks_per_cu = 32 / waves;
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
-    long long grid = (long long)cus * blocks_per_cu;
-    const long long per_block = (long long)waves * (g->pair ? 2 : 1);
-    const long long need = (N + per_block - 1) / per_block;
-    if (grid > need) grid = need;
-    if (grid < 1) grid = 1;
-    g->blocks_a = (int)grid;
-    if (g->pair && g->ns > 1) {
-        // two block roles (see match_stats_kernel); 48 % of the blocks in role A balances the two
-        // loops for 150-base reads in all three modes (measured optimum 45..50 %)
-        if (grid < 2) grid = 2;
-        int pct = 48;
-        if (const char *e = std::getenv("GENIE_PAIR_SPLIT")) { const int v = std::atoi(e); if (v > 0 && v < 100) pct = v; }
-        long long a = (grid * pct + 50) / 100;
-        a = a < 1 ? 1 : (a > grid - 1 ? grid - 1 : a);
-        g->blocks_a = (int)a;
-    }
-    g->sampled = 0;
-    g->win = 0;
-    g->mt = 0;
-    g->recip = 0;
-    if (!g->wide && max_len > 0 && !ix->opt_legacy_search) {
-        // match-table kernel: `grp` reads per wave iteration (about kMtTarget positions: a few passes of
-        // 3 x 64), eight waves per block, nothing block-wide in LDS
-        const int grp = std::min(std::min(kMtMaxG, kWave / mt_pack_dwords(max_len) * 4), std::max(1, (ix->opt_group_positions > 0 ? ix->opt_group_positions : kMtTarget) / max_len));
-        const int wpb = 8;
-        g->mt = grp * max_len;
-        g->grp = grp;
-        g->recip = max_len >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)max_len - 1) / (uint64_t)max_len) : 0u;
-        g->lds = wpb * mt_wave_bytes(grp, max_len, g->qp_recs, g->fwd_stride);
-        g->leaf_in_lds = 0;
-        g->block = wpb * kWave;
-        int bpc = std::min(lds_cap / g->lds, 32 / wpb);
-        if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
-        if (bpc < 1) bpc = 1;
-        long long gr = (long long)cus * bpc;
-        const long long need2 = (N + (long long)wpb * grp - 1) / ((long long)wpb * grp);
-        if (gr > need2) gr = need2;
-        if (gr < 1) gr = 1;
-        g->grid = (int)gr;
-        return GENIE_OK;
-    }
-    if (g->wide && !ix->opt_legacy_search) {
-        // long reads: one wave per read, eight waves per block
-        const int wpb = 8;
-        g->mt = 1;
+    const int wpb = 8;                       // waves per block: nothing block-wide in LDS, no barrier
+    long long per_block;
+    if (g->wide) {
         g->grp = 1;
         g->lds = wpb * mt_long_wave_bytes(max_len, g->qp_recs);
-        g->leaf_in_lds = 0;
-        g->block = wpb * kWave;
-        int bpc = std::min(lds_cap / g->lds, 32 / wpb);
-        if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
-        if (bpc < 1) bpc = 1;
-        long long gr = (long long)cus * bpc;
-        const long long need2 = (N + wpb - 1) / wpb;
-        if (gr > need2) gr = need2;
-        if (gr < 1) gr = 1;
-        g->grid = (int)gr;
-        return GENIE_OK;
+        per_block = wpb;
+    } else {
+        // `grp` reads per wave iteration: about kMtTarget positions (one round-1 pass of 3 x 64 quads), and no
+        // more reads than one pack pass holds
+        const int ml = std::max(max_len, 1);
+        const int grp = ix->opt_group_positions > 0 ? ix->opt_group_positions / ml : kMtTarget / ml;
+        g->grp = std::max(1, std::min(std::min(kMtMaxG, kWave / mt_pack_dwords(ml) * 4), grp));
+        g->lds = wpb * mt_wave_bytes(g->grp, ml, g->qp_recs, g->fwd_stride);
+        per_block = (long long)wpb * g->grp;
     }
-    if (g->wide && (d.flags & kFlagDir16) && !ix->opt_search_all) {
-        // sampled search for long reads: one wave per read, windows of 704 positions
-        const int win = 704;
-        const int ncoarse = ((d.dir_entries - 1) >> 4) + 1;
-        const int dir16 = ((ncoarse * 4 + 15) & ~15) + ((d.dir_entries * 2 + 15) & ~15);
-        const int pw = g->qp_words * 8 + (((win + 8) * 2 + 15) & ~15) + ((win * 2 + 15) & ~15);
-        int w = (lds_cap / 2 - dir16) / pw;
-        int w2 = 1;
-        while (w2 * 2 <= w && w2 < 16) w2 *= 2;
-        if (w >= 4) {
-            int leaf2 = 0;
-            if (mode == GENIE_MODE_RMI) {
-                const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
-                int room = lds_cap / 2 - dir16 - w2 * pw;
-                if (room < 0) room = 0;
-                leaf2 = std::min(cnt, room / 16) * 16;
-            }
-            g->win = win;
-            g->sshift = sample_shift();
-            g->lds = dir16 + leaf2 + w2 * pw;
-            g->leaf_in_lds = leaf2 / 16;
-            g->block = w2 * kWave;
-            long long gr = (long long)cus * 2;
-            const long long need2 = (N + w2 - 1) / w2;
-            if (gr > need2) gr = need2;
-            if (gr < 1) gr = 1;
-            g->grid = (int)gr;
-            return GENIE_OK;
-        }
-    }
-    if (!g->wide && (d.flags & kFlagDir16) && max_len > 0 && !ix->opt_search_all) {
-        // sampled search: directory as 16-bit deltas; `grp` reads per wave with their fwd rows and a work
-        // list: as many as keep two blocks per CU in LDS and fill, not overflow, one 192-entry chunk of
-        // first-round searches
-        const int sshift = sample_shift();
-        const int ncoarse = ((d.dir_entries - 1) >> 4) + 1;
-        const int dir16 = ((ncoarse * 4 + 15) & ~15) + ((d.dir_entries * 2 + 15) & ~15);
-        const int ns0 = ((max_len - 1) >> sshift) + 1;
-        int grp = std::min(8, std::max(1, 192 / ns0));
-        if (const char *e = std::getenv("GENIE_SAMPLE_GROUP")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) grp = v; }   // tuning
-        int wl_cap = 0, pw = 0;
-        for (; grp >= 1; grp--) {
-            wl_cap = grp * max_len;
-            pw = grp * g->qp_words * 8 + 8 * 8 + 32 + ((grp * g->fwd_stride + 15) & ~15) + ((wl_cap * 2 + 15) & ~15);
-            if (dir16 + 16 * pw <= lds_cap / 2) break;
-        }
-        if (grp < 1) grp = 1;
-        int leaf2 = 0;
-        if (mode == GENIE_MODE_RMI) {
-            const int cnt = d.rmi_off[d.nlev] - d.rmi_off[d.nlev - 1];
-            int room = lds_cap / 2 - dir16 - 16 * pw;
-            if (room < 0) room = 0;
-            leaf2 = std::min(cnt, room / 16) * 16;
-        }
-        const int lds2 = dir16 + leaf2 + 16 * pw;
-        if (lds2 <= lds_cap / 2) {
-            g->sampled = wl_cap;
-            g->grp = grp;
-            g->sshift = sshift;
-            g->lds = lds2;
-            g->leaf_in_lds = leaf2 / 16;
-            g->block = 16 * kWave;
-            long long gr = (long long)cus * 2;
-            const long long need2 = (N + 16 * grp - 1) / (16 * grp);
-            if (gr > need2) gr = need2;
-            if (gr < 1) gr = 1;
-            g->grid = (int)gr;
-            return GENIE_OK;
-        }
-    }
-    g->grid = (int)grid;
-    g->block = waves * kWave;
-    g->lds = lds;
-    g->leaf_in_lds = leaf_bytes / 16;     // number of leaf models staged
+    if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
+    g->block = wpb * kWave;
+    int bpc = std::min(lds_cap / g->lds, 32 / wpb);
+    if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
+    if (bpc < 1) bpc = 1;
+    long long gr = (long long)cus * bpc;
+    const long long need = (N + per_block - 1) / per_block;
+    if (gr > need) gr = need;
+    if (gr < 1) gr = 1;
+    g->grid = (int)gr;
     return GENIE_OK;
 }
 
@@ -849,60 +693,37 @@ struct CsrOut {
     int64_t cap_rows = 0;
 };
 
-template <int MODE, int NS, bool WIDE>
+template <int MODE, bool WIDE>
 int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_reads, const int32_t *d_lens, int64_t N,
                     int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts, int32_t *d_slots, int32_t cap,
                     int32_t *d_status, const Workspace &ws, const CsrOut &csr, hipStream_t s)
 {
     int32_t *st = d_status ? d_status : ws.status;
     int32_t *cnt = d_counts ? d_counts : ws.counts;
-    constexpr bool CANPAIR = !WIDE;
-    // the K-mer hash probe (GENIE_OPT_LUT_PROBE) is compiled in only where it is asked for
-    constexpr bool CANPROBE = MODE == GENIE_MODE_LUT;
-    const bool probe = CANPROBE && ix->opt_lut_probe;
-    auto ka = (CANPAIR && g.pair) ? (probe ? match_stats_kernel<MODE, NS, WIDE, CANPAIR, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, CANPAIR, false>)
-                                  : (probe ? match_stats_kernel<MODE, NS, WIDE, false, CANPROBE> : match_stats_kernel<MODE, NS, WIDE, false, false>);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    const long long mtab_bytes = (long long)sizeof(MatchRec) * ix->dev.mtab_entries;
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
-    if (!WIDE && g.mt) {
-        auto km = match_table_kernel;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-        hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
-                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
-                           g.grp, g.max_len, (long long)sizeof(MatchRec) * ix->dev.mtab_entries, ix->opt_debug);
-    } else if (WIDE && g.mt) {
+    if (WIDE) {
         auto km = match_table_long_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
-                           g.max_len, (long long)sizeof(MatchRec) * ix->dev.mtab_entries);
-    } else if (WIDE && g.win) {
-        auto kl = probe ? match_stats_sampled_long_kernel<MODE, CANPROBE> : match_stats_sampled_long_kernel<MODE, false>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-        hipLaunchKernelGGL(kl, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
-                           reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
-                           g.leaf_in_lds, g.sshift, g.win);
-    } else if (!WIDE && g.sampled) {
-        // five reads per wave is what 150-base reads get: that instantiation has the group size folded in
-        auto ks = g.grp == 5 ? (probe ? match_stats_sampled_kernel<MODE, CANPROBE, 5> : match_stats_sampled_kernel<MODE, false, 5>)
-                             : (probe ? match_stats_sampled_kernel<MODE, CANPROBE, 0> : match_stats_sampled_kernel<MODE, false, 0>);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-        hipLaunchKernelGGL(ks, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride, fixed_len,
-                           reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st,
-                           g.leaf_in_lds, g.sampled, g.sshift, g.grp);
-    } else
-    hipLaunchKernelGGL(ka, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, d_reads, d_lens, (long long)N, stride,
-                       fixed_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, g.qp_words, ws.hm, g.hm_words, st, g.leaf_in_lds,
-                       g.blocks_a);
+                           std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
+    } else {
+        auto km = match_table_kernel;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
+                           g.grp, std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_debug << 8);
+    }
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     if (ix->opt_search_only) return GENIE_OK;        // GENIE_OPT_SEARCH_ONLY: timing experiments, workspace only
     auto kb = traverse_kernel<MODE, WIDE>;
     const int tb = 256;
-    const int lds_b = WIDE ? 0 : tb * g.fwd_stride;
+    const int lds_b = WIDE ? 0 : tb * g.fwd_lds;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, cnt, ws.kj, g.kj_row,
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.qp, g.qp_recs, ws.hm, g.hm_words, cnt, ws.kj, g.kj_row,
                        csr.offsets ? g.kj_row : cap, st);
     HIP_TRY(hipGetLastError());
     if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
@@ -941,18 +762,9 @@ int launch_find_mode(const genie_index *ix, const Geometry &g, const uint8_t *d_
     Workspace ws;
     int rc = carve_workspace(d_ws, ws_bytes, N, g, &ws);
     if (rc) return rc;
-#define GENIE_PIPE(NS_, WIDE_)                                                                                        \
-    return launch_pipeline<MODE, NS_, WIDE_>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, \
-                                             cap, d_status, ws, csr, s)
-    if (g.wide) GENIE_PIPE(4, true);
-    switch (g.ns) {
-    case 1: GENIE_PIPE(1, false);
-    case 2: GENIE_PIPE(2, false);
-    case 3: GENIE_PIPE(3, false);
-    case 4: GENIE_PIPE(4, false);
-    }
-#undef GENIE_PIPE
-    return GENIE_E_INVALID;
+    if (g.wide)
+        return launch_pipeline<MODE, true>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, cap, d_status, ws, csr, s);
+    return launch_pipeline<MODE, false>(ix, g, d_reads, d_lens, N, stride, fixed_len, min_len, d_counts, d_slots, cap, d_status, ws, csr, s);
 }
 
 }  // namespace
@@ -973,7 +785,7 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
                         int32_t *lds_bytes)
 {
     Geometry g;
-    int rc = plan_find_smems(ix, mode, max_len, true, 1ll << 40, &g);
+    int rc = plan_find_smems(ix, mode, max_len, 1ll << 40, &g);
     if (rc) return rc;
     if (grid) *grid = g.grid;
     if (block) *block = g.block;
@@ -984,17 +796,11 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
 // Name of the match-statistics kernel the plan picks (as rocprofv3 prints it, without the argument list).
 int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap)
 {
-    Geometry g;
-    int rc = plan_find_smems(ix, mode, max_len, true, 1ll << 40, &g);
-    if (rc) return rc;
-    char tmp[160];
-    if (g.mt) snprintf(tmp, sizeof tmp, g.wide ? "match_table_long_kernel" : "match_table_kernel");
-    else if (g.win) snprintf(tmp, sizeof tmp, "match_stats_sampled_long_kernel<%d, %s>", mode, ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false");
-    else if (g.sampled) snprintf(tmp, sizeof tmp, "match_stats_sampled_kernel<%d, %s, %d>", mode, ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false", g.grp == 5 ? 5 : 0);
-    else snprintf(tmp, sizeof tmp, "match_stats_kernel<%d, %d, %s, %s, %s>", mode, g.ns, g.wide ? "true" : "false", g.pair ? "true" : "false",
-                  ix->opt_lut_probe && mode == GENIE_MODE_LUT ? "true" : "false");
-    if (!buf || cap < (int)strlen(tmp) + 1) return GENIE_E_CAPACITY;
-    memcpy(buf, tmp, strlen(tmp) + 1);
+    (void)ix;
+    (void)mode;
+    const char *name = max_len > 255 ? "match_table_long_kernel" : "match_table_kernel";
+    if (!buf || cap < (int)strlen(name) + 1) return GENIE_E_CAPACITY;
+    memcpy(buf, name, strlen(name) + 1);
     return GENIE_OK;
 }
 
@@ -1016,7 +822,7 @@ static int launch_find_any(const genie_index *ix, int32_t mode, const uint8_t *d
 {
     Geometry g;
     // with ragged lengths `fixed_len` carries the maximum length (host contract)
-    int rc = plan_find_smems(ix, mode, fixed_len, d_lens == nullptr, N, &g);
+    int rc = plan_find_smems(ix, mode, fixed_len, N, &g);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (mode) {
@@ -1113,14 +919,11 @@ int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, i
     }
     const long long nblocks = (N + kScanBlock - 1) / kScanBlock;
     unsigned long long *sums = reinterpret_cast<unsigned long long *>(d_tmp);
-    int *overflow = reinterpret_cast<int *>(sums + nblocks + 1);
-    HIP_TRY(hipMemsetAsync(overflow, 0, 4, s));
     hipLaunchKernelGGL(compact_block_sums, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_counts, (long long)N, cap, sums);
     hipLaunchKernelGGL(compact_scan_sums, dim3(1), dim3(kScanBlock), 0, s, sums, nblocks);
     hipLaunchKernelGGL(compact_scatter, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_counts,
                        reinterpret_cast<const int4 *>(d_slots), (long long)N, cap, sums,
-                       reinterpret_cast<long long *>(d_offsets), reinterpret_cast<int4 *>(d_out), (long long)out_cap_rows,
-                       overflow);
+                       reinterpret_cast<long long *>(d_offsets), reinterpret_cast<int4 *>(d_out), (long long)out_cap_rows);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -219,22 +219,20 @@ int64_t genie_locate_tmp_bytes(int64_t S);
 int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_pos_offsets,
                  int32_t *d_positions, int64_t cap_positions, void *d_tmp, int64_t tmp_bytes, void *stream);
 
-/* Launch-time options of an index handle.
- * GENIE_OPT_LUT_PROBE (default 0): in LUT mode on the short-read path, also probe the K-mer hash
- * table for every read position before the suffix-array search.  Results are identical either
- * way; on MI355X the LDS-staged P-mer directory already narrows a position to a handful of rows,
- * so the extra probe only costs time (measured: DESIGN.md) and is off by default. */
-enum { GENIE_OPT_LUT_PROBE = 1, GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_LEGACY_SEARCH = 3, GENIE_OPT_GROUP_POSITIONS = 4,
-       GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6 };
-/* GENIE_OPT_SEARCH_ALL (default 0): the matching statistics fwd[] are non-decreasing along a read, so by
- * default reads are searched at every 4th position first and only the gaps whose two ends disagree are
- * searched inside (identical results; 1.6x to 3.7x faster on reads that match the reference end to end,
- * ~10 % slower on uniformly random reads).  Value 1 searches every position. */
+/* Launch-time options of an index handle (none of them changes results).
+ * GENIE_OPT_SEARCH_ALL (default 0): the matching statistics fwd[] are non-decreasing along a read, so by default
+ *   the match-statistics kernel looks up every 4th position and the three between two of them only where their
+ *   values differ.  Value 1 looks up every position (differential testing, A/B timing).
+ * GENIE_OPT_GROUP_POSITIONS (default 0 = built-in): read positions a wave works on per iteration (tuning).
+ * GENIE_OPT_SEARCH_BLOCKS_PER_CU (default 0 = as many as fit): cap on resident blocks of that kernel (tuning).
+ * GENIE_OPT_SEARCH_ONLY (default 0): launch the match-statistics kernel only -- outputs are NOT produced; for
+ *   timing that kernel alone. */
+enum { GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_GROUP_POSITIONS = 4, GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6 };
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
 
 /* Profiling hook: two hipEvent_t (as void*, created by the caller with timing enabled) that the next
  * genie_find_smems calls record on their stream immediately before and after the dominant kernel of
- * the path (the suffix-array search, match_stats_kernel).
+ * the path (the match-statistics kernel, match_table_kernel / match_table_long_kernel).
  * Pass NULLs to stop.  Not thread-safe with concurrent launches on the same handle. */
 int genie_index_set_stage_events(genie_index *ix, void *ev_search_begin, void *ev_search_end);
 

@@ -280,9 +280,9 @@ def test_vs_oracle_fresh_reads(pkg, oracle_mod, ds, L, kind, algo):
 @pytest.mark.parametrize("search_all", [0, 1])
 @pytest.mark.parametrize("algo", ["bwa", "lut", "rmi"])
 def test_fixed_length_slot_layouts(pkg, oracle_mod, algo, search_all):
-    """Fixed-length batches whose last 64-position slot holds at most 32 positions are searched two reads
-    per wave with a shared slot; lengths on both sides of every boundary, an odd batch (last read has
-    no partner), and flagged reads inside pairs."""
+    """Fixed-length batches of every length around the group / quad / 64-position boundaries of the search
+    kernel, odd batch sizes (a last, partly filled group) and flagged reads inside groups; with the sampled
+    lookup (default) and with every position looked up (GENIE_OPT_SEARCH_ALL)."""
     from genie_smem_amd import synth as B
     d, _ = G.load("syn100k_K15")
     ix = _index_for(pkg, "syn100k_K15", algo)
@@ -380,9 +380,9 @@ def test_long_exact_matches_and_low_complexity(pkg, oracle_mod, ds):
 
 @pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
 def test_sampled_search_equals_full_search(pkg, oracle_mod, ds):
-    """Default search (every 4th position, then only the gaps whose ends disagree) against
-    GENIE_OPT_SEARCH_ALL on from-ref, random, exact and ragged batches, all modes; one batch also
-    against the CPU oracle so that both are pinned."""
+    """Default search (every 4th position looked up, the three between two of them only where their values
+    differ) against GENIE_OPT_SEARCH_ALL (every position looked up) on from-ref, random, exact and ragged
+    batches, all modes; one batch also against the CPU oracle so that both are pinned."""
     import torch
     from genie_smem_amd import synth as B
     d, _ = G.load(ds)
@@ -510,21 +510,6 @@ def test_sampled_search_fuzz_lengths(pkg):
         finally:
             h.set_option(pkg._native.OPT_SEARCH_ALL, 0)
         assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (it, algo, L, N)
-
-
-def test_lut_probe_option_changes_nothing(pkg):
-    from genie_smem_amd import synth as B
-    d, _ = G.load("syn100k_K15")
-    ix = _index(pkg, "syn100k_K15")
-    rd = B.reads_from_ref(d["ref_codes"], 3000, 150, 77)
-    a = ix.find_smems("lut", rd)
-    ix.set_option(pkg._native.OPT_LUT_PROBE, 1)
-    try:
-        b = ix.find_smems("lut", rd)
-    finally:
-        ix.set_option(pkg._native.OPT_LUT_PROBE, 0)
-    import torch
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_ragged_and_status(pkg, oracle_mod):

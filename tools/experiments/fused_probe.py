@@ -2,7 +2,7 @@
 that returned wrong intervals in round 1) against the three-kernel pipeline, same reads, 1M x 150 bp."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import genie_smem_amd as g
 from genie_smem_amd import synth
 n, N, L = 100_000, 1_000_000, 150
