@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per step: per GPU (configs 1-3) or in all (config 4)")
     ap.add_argument("--read-len", type=int, default=None, help="off-config read length (sweeps only; named in config.workload)")
     ap.add_argument("--read-kind", default="fromref", choices=["fromref", "random"], help="off-config read distribution (sweeps only)")
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--search-all", action="store_true", help="GENIE_OPT_SEARCH_ALL: look up every position, no sampling (A/B runs)")

@@ -173,13 +173,13 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
         }
 
         // Second-level range table: for every P2-mer the exact rows [lb, ub) whose suffix starts with it
-        // (rows sharing a prefix are contiguous).  P2 = smallest with 4^P2 >= n/2 (and > P), i.e. <= 2 rows
+        // (rows sharing a prefix are contiguous).  P2 = smallest with 4^P2 >= n/4 (and > P), i.e. <= 4 rows
         // per entry on average.  The match table has the same index: per P2-mer the 16-base continuations
         // of (up to kMatchKeys of) its suffixes, in ONE 32-byte entry -- what the match-statistics kernel
         // reads instead of searching rows.
         {
             int P2 = P + 1;
-            while (P2 < 12 && ((int64_t)1 << (2 * P2)) < n / 2) P2++;
+            while (P2 < 12 && ((int64_t)1 << (2 * P2)) < n / 4) P2++;
             if (dir2_bits > P && dir2_bits <= 12) P2 = dir2_bits;       // build-time tuning (genie_index_create_ex)
             h->P2 = P2;
             const int64_t nb2 = (int64_t)1 << (2 * P2);

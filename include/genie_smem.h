@@ -99,7 +99,7 @@ int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *s
                                int32_t dir_bits, genie_index **out);
 
 /* genie_index_create / _from_sa (sa_one_based may be NULL) with the size of the per-P2-mer tables chosen by
- * the caller: table_bits = P2 in (dir_bits, 12], 0 = automatic (smallest P2 with 4^P2 >= n/2).  A tuning
+ * the caller: table_bits = P2 in (dir_bits, 12], 0 = automatic (smallest P2 with 4^P2 >= n/4: measured best on MI355X at n = 100 kb and 1 Mb).  A tuning
  * knob of the index image only: results do not depend on it. */
 int genie_index_create_ex(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t dir_bits,
                           int32_t table_bits, genie_index **out);

@@ -233,6 +233,33 @@ def test_rmi_fit_is_a_usable_model(pkg):
     assert r.rmi_predict(q).shape == (1,)
 
 
+@pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
+def test_native_rmi_fit_against_reference_sklearn_coefficients(pkg, ds):
+    """genie_index_train_rmi against the models the REFERENCE fitted with scikit-learn (RMI.fit, SMEM/RMI.py:10-50;
+    coefficients exported into the fixtures by make_golden.py): on the fixture K-mers the two models' predictions
+    differ by less than one suffix-array row -- the fits differ in least-squares arithmetic only.  (Results cannot
+    depend on it: a prediction only picks where a bounded search starts.)"""
+    d, _ = G.load(ds)
+    ref, K = d["ref_codes"], int(d["K"])
+    for tag in sorted({k.split(".")[0] for k in d if k.startswith("g4_")}):
+        experts = [int(x) for x in d[tag + ".experts"]]
+        coefs = [d[f"{tag}.coef{l}"] for l in range(len(experts) + 1)]
+        icpts = [d[f"{tag}.icpt{l}"] for l in range(len(experts) + 1)]
+        ix = pkg.GenieIndex.build(ref, K)
+        ncoefs, nicpts, _, _, _ = ix.train_rmi(experts)
+        assert [len(c) for c in ncoefs] == [len(c) for c in coefs]
+        kmers = d[tag + ".kmers"].astype(np.int64)
+        key = np.zeros(len(kmers), np.int64)
+        for j in range(K):
+            key = (key << 2) | kmers[:, j]
+        p_ref = pkg.RMI.from_coefficients(experts, coefs, icpts).predict(key)
+        assert np.array_equal(p_ref, d[tag + ".pred"])                      # the fixture's own float64 predictions
+        p_nat = pkg.RMI.from_coefficients(experts, ncoefs, nicpts).predict(key)
+        # K-mers routed to the same leaf by both models (a boundary K-mer may go to the neighbouring leaf)
+        delta = np.abs(p_nat - p_ref)
+        assert np.median(delta) < 1e-2 and (delta < 1.0).mean() > 0.995, (tag, np.median(delta), (delta < 1.0).mean())
+
+
 def test_native_rmi_training(pkg):
     """genie_index_train_rmi (C++) against the numpy restatement of RMI.fit on the same pairs: same
     structure, near-identical predictions, and leaf error bounds that do bound every training pair."""

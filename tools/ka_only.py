@@ -7,8 +7,9 @@ from genie_smem_amd import synth
 n = int(os.environ.get("REF_N", 100_000)); N = int(os.environ.get("READS", 1_000_000)); L = int(os.environ.get("READ_LEN", 150))
 mode = os.environ.get("MODE", "lut")
 ref = synth.synth_ref(n, n)
-m = g.ExactMatch("x.fa", device="cuda:0"); m.set_reference("".join("ACGT"[c] for c in ref))
-rl = g.RMI_LUT([1000], 15, "x.fa", matcher=m); rl.train_RMI(); ix = rl._index()
+ix = g.GenieIndex.build(ref, 15, table_bits=int(os.environ.get("TABLE_BITS", "0")))
+ix.train_rmi([1000])
+ix = ix.to("cuda")
 kind = os.environ.get("KIND", "fromref")
 if kind == "random":
     reads = torch.as_tensor(np.random.default_rng(7).integers(0, 4, (N, L)).astype(np.uint8)).cuda()
