@@ -608,7 +608,7 @@ inline void shape_for(int max_len, Geometry *g)
     int dw = std::max(1, (max_len + 3) / 4);
     if ((dw & 1) == 0) dw++;
     g->fwd_lds = dw * 4;
-    g->kj_row = (std::max(max_len, 1) + 7) & ~7;
+    g->kj_row = (std::max(max_len, 1) + 1 + 7) & ~7;      // entry 0 = the count
 }
 
 int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
@@ -730,26 +730,18 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         int rc = launch_compact(cnt, nullptr, N, g.kj_row, csr.offsets, nullptr, 0, ws.scan_tmp, s);
         if (rc) return rc;
     }
-    // K_C: intervals + final rows, 16 lanes per read, persistent blocks with the directory in LDS
-    const int lds_c = (ix->dev.dir_entries * 4 + 15) & ~15;
+    // K_C: intervals + final rows, 16 lanes per read (4 reads per wave pass), persistent blocks
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
-    int blocks_c = 160 * 1024 / lds_c;
-    blocks_c = blocks_c > 2 ? 2 : (blocks_c < 1 ? 1 : blocks_c);
-    long long grid_c = (long long)cus * blocks_c;
-    const long long need_c = (N + 63) / 64;
+    long long grid_c = (long long)cus * (32 / kIvWaves);
+    const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
-    if (csr.offsets) {
-        auto kc = interval_kernel<true, WIDE>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
-        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, g.kj_row,
-                           ws.qp, g.qp_recs, reinterpret_cast<int4 *>(csr.rows), 0,
+    if (csr.offsets)
+        hipLaunchKernelGGL((interval_kernel<true, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
+                           ws.kj, g.kj_row, ws.qp, g.qp_recs, reinterpret_cast<int4 *>(csr.rows), 0,
                            reinterpret_cast<const long long *>(csr.offsets), (long long)csr.cap_rows);
-    } else {
-        auto kc = interval_kernel<false, WIDE>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, lds_c));
-        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(1024), lds_c, s, ix->dev, (long long)N, cnt, ws.kj, g.kj_row,
-                           ws.qp, g.qp_recs, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
-    }
+    else
+        hipLaunchKernelGGL((interval_kernel<false, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
+                           ws.kj, g.kj_row, ws.qp, g.qp_recs, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -150,3 +150,22 @@ def test_query_generators(pkg):
     assert len(q) == 40 and set(q) <= set("ACGT")
     q2 = pkg.create_query_from_ref("ACGTTGCATGCAGTCAGTCGATCGATGCATGCATGCAAGTC", 25)
     assert len(q2) == 25
+
+
+def test_workspace_rows_and_index_create_ex_arguments():
+    """Host-only ABI entry points: per-read workspace rows (traffic accounting) and argument checks of
+    genie_index_create_ex (no GPU involved)."""
+    import ctypes as C
+    import genie_smem_amd as pkg
+    w = pkg.GenieIndex.workspace_shape(150)
+    assert w == {"fwd_stride": 160, "qp_recs": 6, "hm_words": 4, "kj_row_bytes": 2 * 152}
+    w = pkg.GenieIndex.workspace_shape(2000)
+    assert w["fwd_stride"] == 4000 and w["qp_recs"] == 63 and w["hm_words"] == 33
+    lib = pkg._native.lib()
+    assert lib.genie_find_smems_workspace_rows(-1, (C.c_int32 * 4)()) == -1
+    codes = np.zeros(64, np.uint8)
+    h = C.c_void_p()
+    u8p = C.POINTER(C.c_uint8)
+    assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 7, 13, C.byref(h)) == -1      # table_bits out of range
+    assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 7, 9, C.byref(h)) == 0
+    lib.genie_index_destroy(h)
