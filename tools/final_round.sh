@@ -1,0 +1,19 @@
+# Round-end records: bench lines of every config (+ BWA mode), the read-length / read-kind sweep, then the profile
+# passes of configs 1-3.  usage (on the GPU box): bash tools/final_round.sh <tag>  -> gpurun_out/final_<tag>/, gpurun_out/prof_<tag>_cfg*/
+TAG=$1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p $O
+timeout -k 10 500 python bench.py > $O/bench_cfg1.json 2> $O/bench_cfg1.err || exit 1
+timeout -k 10 500 python bench.py --config 2 > $O/bench_cfg2.json 2> $O/bench_cfg2.err || exit 1
+timeout -k 10 300 python bench.py --mode bwa --no-cpu-baseline --no-from-host > $O/bench_bwa.json 2> $O/bench_bwa.err || exit 1
+timeout -k 10 600 python bench.py --config 3 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err || exit 1
+timeout -k 10 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err || exit 1
+bash tools/sweep_read_len.sh > $O/sweep.txt 2>&1 || exit 1
+cp $R/gpurun_out/sweep/summary.json $O/read_len_sweep.json
+for c in 1 2 3; do bash tools/profile_round.sh ${TAG}_cfg$c --config $c > $O/prof_cfg$c.txt 2>&1 || exit 1; done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/bench_*.json")):
+    j = json.load(open(f)); r = j["roofline"]
+    print(f.split("/")[-1], "%.1f G" % (j["value"] / 1e9), "%.3f ms" % j["ms_per_step"], "K_A %.3f" % r["kernel_ms_avg"], "frac %.3f" % r["frac"],
+          (j.get("value_from_host") or {}).get("value"), (j.get("cpu_baseline") or {}).get("value"))
+PY
