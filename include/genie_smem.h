@@ -226,8 +226,12 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  * GENIE_OPT_GROUP_POSITIONS (default 0 = built-in): read positions a wave works on per iteration (tuning).
  * GENIE_OPT_SEARCH_BLOCKS_PER_CU (default 0 = as many as fit): cap on resident blocks of that kernel (tuning).
  * GENIE_OPT_SEARCH_ONLY (default 0): launch the match-statistics kernel only -- outputs are NOT produced; for
- *   timing that kernel alone. */
-enum { GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_GROUP_POSITIONS = 4, GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6 };
+ *   timing that kernel alone.
+ * GENIE_OPT_SEARCH_STAGES_OFF (default 0; honoured only while GENIE_OPT_SEARCH_ONLY is set, so never on a run that
+ *   produces output): bit mask of stages of that kernel to skip -- 1 slow list, 2 round 2, 4 rounds 1+2, 8 packed-read
+ *   records, 16 hit-mask words, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh). */
+enum { GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_GROUP_POSITIONS = 4, GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6,
+       GENIE_OPT_SEARCH_STAGES_OFF = 7 };
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
 
 /* Profiling hook: two hipEvent_t (as void*, created by the caller with timing enabled) that the next

@@ -555,6 +555,25 @@ def test_absent_base_is_flagged(pkg):
 
 
 # ------------------------------------------------------------------ multi-GPU plumbing on one GPU
+def test_report_helpers(pkg):
+    """genie_search_kernel_name / genie_launch_info: what bench.py and the profile summaries key on."""
+    ix = _index(pkg, "syn10k_K8")
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel"
+    assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel"
+    info = ix.launch_info("lut", 150)
+    assert info["block"] == 512 and 0 < info["lds_bytes"] <= 160 * 1024 and info["grid"] > 0
+    # the stage switches are ignored unless the search kernel runs alone
+    ix.set_option(pkg._native.OPT_SEARCH_STAGES_OFF, 63)
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn10k_K8")
+    rd = B.reads_from_ref(d["ref_codes"], 200, 100, 5)
+    a = ix.find_smems("lut", rd)
+    ix.set_option(pkg._native.OPT_SEARCH_STAGES_OFF, 0)
+    b = ix.find_smems("lut", rd)
+    import torch
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_handle_opened_from_image(pkg):
     """What ranks != 0 do in the sharded run: open a device-resident copy of the serialized image
     (genie_index_open) and search with it -- same rows as the handle that built the index."""
