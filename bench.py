@@ -291,7 +291,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         shape = ix.workspace_shape(L)           # bytes per read of the hand-off rows
         # COMPULSORY HBM bytes per read: what a kernel must read and write (inputs + hand-offs + outputs)
-        search_bytes = L + 4 + shape["fwd_stride"] + 16 * shape["qp_recs"] + 8 * shape["hm_words"]
+        search_bytes = L + 4 + shape["fwd_stride"] + 16 * shape["qp_recs"] + shape["mmax_bytes"]
         step_bytes = L + 16.0 * S + 12            # reads in, (start, end, lo, hi) rows + offset + status out
         key = f"config{args.config}:{mode}:{n_reads}" + ("" if not offcfg else ":" + ",".join(offcfg))
         ctr = load_counters(key)
@@ -300,8 +300,8 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_read": search_bytes,
                 "kernel_ms_avg": kern_ms_avg, "kernel_ms_min": float(np.min(kern_ms)),
-                "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, hit "
-                              "masks, status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
+                "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, longest "
+                              "match, status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
                               "not by HBM (see `binding`)",
                 "step": {"kernels": "match statistics + traversal + offsets scan + interval search -> CSR rows",
                          "ms_avg": path_ms_avg, "compulsory_bytes_per_read": step_bytes,

@@ -591,7 +591,6 @@ struct Geometry {
     int fwd_stride;  // bytes per fwd[] row in the workspace
     int fwd_lds;     // bytes per fwd[] row in K_B's LDS copy (narrow): an odd number of dwords
     int qp_recs;     // 16-byte packed-read records per read in the workspace
-    int hm_words;    // hit-mask words per read + 1 (longest match)
     int kj_row;      // emitted-pair entries per read
 };
 
@@ -599,9 +598,7 @@ inline void shape_for(int max_len, Geometry *g)
 {
     g->max_len = max_len;
     g->wide = max_len > 255;
-    const int ns = g->wide ? (max_len + 63) / 64 : std::max(1, (max_len + 63) / 64);
-    g->qp_recs = g->wide ? (max_len + 31) / 32 : 2 * ns;
-    g->hm_words = ns + 1;
+    g->qp_recs = g->wide ? (max_len + 31) / 32 : 2 * std::max(1, (max_len + 63) / 64);
     // rows are multiples of 16 bytes (K_A copies them out 16 bytes per lane); K_B's LDS rows are an odd number of
     // dwords, so that lanes reading the same offset of their own rows hit distinct banks
     g->fwd_stride = g->wide ? ((max_len * 2) + 15) & ~15 : std::max(16, (max_len + 15) & ~15);
@@ -650,7 +647,7 @@ struct Workspace {
     RefRec *qp;          // qp_recs records of 16 bytes per read
     int32_t *status;     // used when the caller passes no status array
     uint8_t *kj;         // N x kj_row emitted (start | end << shift) entries of 2 or 4 bytes
-    unsigned long long *hm;  // N x hm_words: K-mer hit mask per 64 positions + longest match
+    uint32_t *mmax;      // N: an upper bound of the longest match in the read (bounds K_B's bisection windows)
     int32_t *counts;     // used by the CSR entry point
     uint8_t *scan_tmp;   // scratch of the offsets scan (CSR entry point)
 };
@@ -662,7 +659,7 @@ inline int64_t workspace_bytes_for(int64_t N, int max_len)
     Geometry g;
     shape_for(max_len, &g);
     return ws_align(N * (int64_t)g.fwd_stride) + ws_align(N * (int64_t)g.qp_recs * 16) + ws_align(N * 4) +
-           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * (int64_t)g.hm_words * 8) + ws_align(N * 4) +
+           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * 4) + ws_align(N * 4) +
            ws_align(compact_tmp_bytes(N)) + 256;
 }
 
@@ -679,8 +676,8 @@ inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geomet
     p += ws_align(N * 4);
     ws->kj = p;
     p += ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2));
-    ws->hm = reinterpret_cast<unsigned long long *>(p);
-    p += ws_align(N * (int64_t)g.hm_words * 8);
+    ws->mmax = reinterpret_cast<uint32_t *>(p);
+    p += ws_align(N * 4);
     ws->counts = reinterpret_cast<int32_t *>(p);
     p += ws_align(N * 4);
     ws->scan_tmp = p;
@@ -706,13 +703,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         auto km = match_table_long_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
-                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.mmax, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
         auto km = match_table_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
-                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.hm, g.hm_words, st,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.mmax, st,
                            g.grp, std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_debug << 8);
     }
     HIP_TRY(hipGetLastError());
@@ -723,7 +720,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     const int lds_b = WIDE ? 0 : tb * g.fwd_lds;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.qp, g.qp_recs, ws.hm, g.hm_words, cnt, ws.kj, g.kj_row,
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.mmax, cnt, ws.kj, g.kj_row,
                        csr.offsets ? g.kj_row : cap, st);
     HIP_TRY(hipGetLastError());
     if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
@@ -804,7 +801,7 @@ void find_smems_workspace_rows(int32_t max_len, int32_t out[4])
     shape_for(max_len, &g);
     out[0] = g.fwd_stride;
     out[1] = g.qp_recs;
-    out[2] = g.hm_words;
+    out[2] = 4;                      // the longest-match word
     out[3] = g.kj_row * (g.wide ? 4 : 2);
 }
 

@@ -184,8 +184,8 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
  * the kernels of the pipeline). */
 int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len);
 /* Per-read rows of that workspace, for traffic accounting: out[0] = bytes of a matching-statistics (fwd) row,
- * out[1] = 16-byte packed-read records, out[2] = 8-byte hit-mask words (+1: longest match), out[3] = bytes of
- * the emitted (start, end) pair row. */
+ * out[1] = 16-byte packed-read records, out[2] = bytes of the longest-match word, out[3] = bytes of the emitted
+ * (count, (start, end) pairs) row. */
 int genie_find_smems_workspace_rows(int32_t max_len, int32_t *row_bytes4);
 int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,
                      int64_t N, int32_t stride, int32_t fixed_len, int32_t min_len, int32_t *d_counts,
@@ -229,7 +229,7 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  *   timing that kernel alone.
  * GENIE_OPT_SEARCH_STAGES_OFF (default 0; honoured only while GENIE_OPT_SEARCH_ONLY is set, so never on a run that
  *   produces output): bit mask of stages of that kernel to skip -- 1 slow list, 2 round 2, 4 rounds 1+2, 8 packed-read
- *   records, 16 hit-mask words, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh). */
+ *   records, 16 longest-match words, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh). */
 enum { GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_GROUP_POSITIONS = 4, GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6,
        GENIE_OPT_SEARCH_STAGES_OFF = 7 };
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
