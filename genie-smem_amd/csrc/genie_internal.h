@@ -14,7 +14,7 @@ struct uint2 { unsigned int x, y; };
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 7;
+constexpr uint32_t kBlobVersion = 8;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -43,7 +43,8 @@ constexpr int32_t kFlagDir16 = 1;
 //                       short: key[kMatchKeys - 1] is the index (in 32-byte entries from the table start) of
 //                       overflow entries holding keys kMatchKeys - 1, kMatchKeys, ... eight per entry
 //   meta byte 3  rows   min(number of suffixes, 255)
-//   lb                  suffix-array row of the first of them (rows of one P2-mer are contiguous)
+//   lb                  suffix-array row of the first of them (rows of one P2-mer are contiguous); an ABSENT
+//                       P2-mer (rows = 0, base >= 1): lb .. key[0] are the rows of its longest occurring prefix
 //   key[i]              the 16 bases that FOLLOW the first P2 bases of suffix-array row lb + i (so the keys
 //                       ascend), packed like the reference (base j in bits [30-2j, 31-2j]); unused slots
 //                       repeat key[0].  meta, lb, key[0..1] are the first 16 bytes: most positions need no
@@ -51,7 +52,8 @@ constexpr int32_t kFlagDir16 = 1;
 // The longest match of a query position is  min(base + max_i lcp(query key, key[i]), bases left)  unless
 // the entry is slow or a key agrees in all 16 bases with more of the read left: then the suffix-array
 // rows lb + i whose keys agree (or, for a slow entry, a search of all its rows) decide.  The rows that hold
-// a pattern of P2 .. P2 + 16 bases are lb + i for the keys that agree with it that far (interval search).
+// a pattern of P2 .. P2 + 16 bases are lb + i for the keys that agree with it that far (interval search); a
+// LONGER pattern that is known to occur and whose first P2 + 16 bases single out one key is that one row.
 constexpr int kMatchKeys = 6;
 constexpr uint32_t kMatchSlow = 1u << 16;
 constexpr uint32_t kMatchMore = 1u << 17;

@@ -234,25 +234,36 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                     reinterpret_cast<uint32_t *>(&h->mtab[(size_t)h->mtab[(size_t)c].key[kMatchKeys - 1] + o / 8])[o % 8] = key;
                 }
             }
-            // which t-mers (t < P2) occur anywhere in the reference, its last bases included
-            std::vector<std::vector<uint8_t>> occ((size_t)P2);
+            // the rows of every t-mer (t < P2) that occurs anywhere in the reference, its last bases included:
+            // rows sharing a prefix are contiguous, so first row + count
+            std::vector<std::vector<uint32_t>> tfirst((size_t)P2), tcnt((size_t)P2);
             for (int t = 1; t < P2; t++) {
-                occ[(size_t)t].assign((size_t)1 << (2 * t), 0);
-                if (t > n) continue;
-                uint64_t code = 0;
-                const uint64_t mask = ((uint64_t)1 << (2 * t)) - 1;
-                for (int64_t i = 0; i < n; i++) {
-                    code = ((code << 2) | codes[i]) & mask;
-                    if (i >= t - 1) occ[(size_t)t][(size_t)code] = 1;
+                tfirst[(size_t)t].assign((size_t)1 << (2 * t), 0);
+                tcnt[(size_t)t].assign((size_t)1 << (2 * t), 0);
+            }
+            for (int64_t r = 0; r < rows; r++) {
+                const int64_t s = h->sa0[(size_t)r];
+                const int tmax = (int)std::min<int64_t>(P2 - 1, n - s);
+                if (tmax < 1) continue;
+                const uint64_t c = code_at64(codes, s, tmax);
+                for (int t = 1; t <= tmax; t++) {
+                    const size_t x = (size_t)(c >> (2 * (tmax - t)));
+                    if (tcnt[(size_t)t][x]++ == 0) tfirst[(size_t)t][x] = (uint32_t)r;
                 }
             }
             for (int64_t c = 0; c < nb2; c++) {
                 MatchRec &m = h->mtab[(size_t)c];
                 const uint32_t k = cnt[(size_t)c];
                 if (k == 0) {
+                    // absent: the longest prefix that does occur, and (for the interval kernel) that prefix's rows
                     int t = P2 - 1;
-                    while (t >= 1 && !occ[(size_t)t][(size_t)((uint64_t)c >> (2 * (P2 - t)))]) t--;
+                    while (t >= 1 && !tcnt[(size_t)t][(size_t)((uint64_t)c >> (2 * (P2 - t)))]) t--;
                     m.meta = (uint32_t)t;                                // lmask = 0, flags = 0, rows = 0
+                    if (t >= 1) {
+                        const size_t x = (size_t)((uint64_t)c >> (2 * (P2 - t)));
+                        m.lb = tfirst[(size_t)t][x];
+                        m.key[0] = m.lb + tcnt[(size_t)t][x] - 1;        // last row (inclusive)
+                    }
                 } else {
                     const bool chain = !cut[(size_t)c] && k > (uint32_t)kMatchKeys && k <= (uint32_t)kMatchChainRows;
                     for (uint32_t i = k; i < (uint32_t)kMatchKeys; i++) m.key[i] = m.key[0];

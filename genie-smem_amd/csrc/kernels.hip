@@ -591,6 +591,8 @@ struct Geometry {
     int fwd_stride;  // bytes per fwd[] row in the workspace
     int fwd_lds;     // bytes per fwd[] row in K_B's LDS copy (narrow): an odd number of dwords
     int qp_recs;     // 16-byte packed-read records per read in the workspace
+    int qp_stride;   // records per read SLOT: short reads keep the head of the (count, pairs) row behind the records,
+                     // slots padded to whole 64-byte lines (K_C's count, pairs and window come from one line)
     int kj_row;      // emitted-pair entries per read
 };
 
@@ -606,6 +608,7 @@ inline void shape_for(int max_len, Geometry *g)
     if ((dw & 1) == 0) dw++;
     g->fwd_lds = dw * 4;
     g->kj_row = (std::max(max_len, 1) + 1 + 7) & ~7;      // entry 0 = the count
+    g->qp_stride = g->wide ? g->qp_recs : ((g->qp_recs * 16 + kPairHeadWords * 8 + 63) & ~63) / 16;
 }
 
 int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)
@@ -658,7 +661,7 @@ inline int64_t workspace_bytes_for(int64_t N, int max_len)
 {
     Geometry g;
     shape_for(max_len, &g);
-    return ws_align(N * (int64_t)g.fwd_stride) + ws_align(N * (int64_t)g.qp_recs * 16) + ws_align(N * 4) +
+    return ws_align(N * (int64_t)g.fwd_stride) + ws_align(N * (int64_t)g.qp_stride * 16) + ws_align(N * 4) +
            ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * 4) + ws_align(N * 4) +
            ws_align(compact_tmp_bytes(N)) + 256;
 }
@@ -671,7 +674,7 @@ inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geomet
     ws->fwd = p;
     p += ws_align(N * (int64_t)g.fwd_stride);
     ws->qp = reinterpret_cast<RefRec *>(p);
-    p += ws_align(N * (int64_t)g.qp_recs * 16);
+    p += ws_align(N * (int64_t)g.qp_stride * 16);
     ws->status = reinterpret_cast<int32_t *>(p);
     p += ws_align(N * 4);
     ws->kj = p;
@@ -709,18 +712,21 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         auto km = match_table_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
-                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.mmax, st,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, ws.mmax, st,
                            g.grp, std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_debug << 8);
     }
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
     if (ix->opt_search_only) return GENIE_OK;        // GENIE_OPT_SEARCH_ONLY: timing experiments, workspace only
+    // the head of a read's (count, pairs) row: behind its packed-read records (short reads) or the kj row itself
+    uint8_t *head = WIDE ? ws.kj : reinterpret_cast<uint8_t *>(ws.qp) + g.qp_recs * 16;
+    const int head_stride = WIDE ? g.kj_row * 4 : g.qp_stride * 16;
     auto kb = traverse_kernel<MODE, WIDE>;
     const int tb = 256;
     const int lds_b = WIDE ? 0 : tb * g.fwd_lds;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
     hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.mmax, cnt, ws.kj, g.kj_row,
+                       fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.mmax, cnt, ws.kj, g.kj_row, head, head_stride,
                        csr.offsets ? g.kj_row : cap, st);
     HIP_TRY(hipGetLastError());
     if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
@@ -734,11 +740,11 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     if (grid_c > need_c) grid_c = need_c;
     if (csr.offsets)
         hipLaunchKernelGGL((interval_kernel<true, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
-                           ws.kj, g.kj_row, ws.qp, g.qp_recs, reinterpret_cast<int4 *>(csr.rows), 0,
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(csr.rows), 0,
                            reinterpret_cast<const long long *>(csr.offsets), (long long)csr.cap_rows);
     else
         hipLaunchKernelGGL((interval_kernel<false, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
-                           ws.kj, g.kj_row, ws.qp, g.qp_recs, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

@@ -416,6 +416,9 @@ def test_match_table_against_brute_force(pkg, case):
         mer = "".join("ACGT"[(int(c) >> (2 * (P2 - 1 - j))) & 3] for j in range(P2))
         t = max([t for t in range(1, P2) if mer[:t] in occ[t]], default=0)
         assert base[c] == t and slow[c] == 0 and rows[c] == 0, mer
+        if t:                                    # the rows of the longest occurring prefix (the interval kernel's answer)
+            want = [row for row, st in enumerate(sa0) if s[st:st + t] == mer[:t]]
+            assert (int(mt["lb"][c]), int(mt["key"][c][0])) == (want[0], want[-1]) and len(want) == want[-1] - want[0] + 1, mer
 
 
 def test_corrupt_image_is_rejected(pkg):
