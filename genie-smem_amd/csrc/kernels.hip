@@ -687,6 +687,10 @@ inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geomet
     return GENIE_OK;
 }
 
+// long reads: 8 lanes per read once that still leaves a wave for every slot of the chip (measured, from-ref reads:
+// 3 x 10^5 x 500 bases 432 -> 349 us, 75 000 x 2000 bases 438 -> 415 us, but 18 750 x 8000 bases 549 -> 659 us)
+constexpr long long kLongEightLaneReads = 65536;
+
 struct CsrOut {
     int64_t *offsets = nullptr;      // non-null => write CSR rows to `rows`, else slots
     int32_t *rows = nullptr;
@@ -721,13 +725,21 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     // the head of a read's (count, pairs) row: behind its packed-read records (short reads) or the kj row itself
     uint8_t *head = WIDE ? ws.kj : reinterpret_cast<uint8_t *>(ws.qp) + g.qp_recs * 16;
     const int head_stride = WIDE ? g.kj_row * 4 : g.qp_stride * 16;
-    auto kb = traverse_kernel<MODE, WIDE>;
     const int tb = 256;
-    const int lds_b = WIDE ? 0 : tb * g.fwd_lds;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
-    hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                       fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.mmax, cnt, ws.kj, g.kj_row, head, head_stride,
-                       csr.offsets ? g.kj_row : cap, st);
+    if (WIDE) {                              // 8 lanes per read; 16 when the batch is too small to fill the chip otherwise
+        const int lanes = N >= kLongEightLaneReads ? 8 : 16;
+        auto kl = lanes == 8 ? traverse_long_kernel<MODE, 8> : traverse_long_kernel<MODE, 16>;
+        hipLaunchKernelGGL(kl, dim3((unsigned)((N + tb / lanes - 1) / (tb / lanes))), dim3(tb), 0, s, d_lens,
+                           (long long)N, fixed_len, min_len, ws.fwd, g.fwd_stride, cnt, reinterpret_cast<uint32_t *>(ws.kj),
+                           g.kj_row, csr.offsets ? g.kj_row : cap, st);
+    } else {                                 // one lane per read, rows staged in LDS
+        auto kb = traverse_kernel<MODE>;
+        const int lds_b = tb * g.fwd_lds;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
+                           fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.mmax, cnt, ws.kj, g.kj_row, head, head_stride,
+                           csr.offsets ? g.kj_row : cap, st);
+    }
     HIP_TRY(hipGetLastError());
     if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
         int rc = launch_compact(cnt, nullptr, N, g.kj_row, csr.offsets, nullptr, 0, ws.scan_tmp, s);

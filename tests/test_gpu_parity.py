@@ -379,6 +379,56 @@ def test_long_exact_matches_and_low_complexity(pkg, oracle_mod, ds):
 
 
 @pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
+def test_long_reads_vs_oracle(pkg, oracle_mod, ds):
+    """Reads of 256 .. 8192 bases (the 16-lanes-per-read traversal, windows of 704 positions in the match
+    statistics): from-ref, random, reference substrings (one match spanning many 32-position passes), the same
+    with substitutions, low complexity, ragged lengths and a BWA length filter -- against the CPU oracle."""
+    d, _ = G.load(ds)
+    ref = d["ref_codes"]
+    n = len(ref)
+    rng = np.random.default_rng(31)
+    from genie_smem_amd import synth as B
+    o = oracle_mod.Oracle(ref, 15)
+    o.set_rmi([], [np.asarray([o.n / 4.0 ** o.K])], [np.asarray([0.0])])
+    for L, nr in ((256, 40), (1000, 30), (4097, 12), (8192, 8)):
+        exact = np.stack([ref[s0:s0 + L] for s0 in rng.integers(0, n - L, nr // 2)]).astype(np.uint8)
+        mut = exact.copy()
+        for row in mut:
+            pos = rng.integers(0, L, max(1, L // 300))
+            row[pos] = (row[pos] + 1 + rng.integers(0, 3, len(pos))) % 4
+        low = np.stack([np.full(L, 1, np.uint8), np.tile(np.asarray([3, 0, 0, 1, 1, 1], np.uint8), L // 6 + 1)[:L]])
+        batch = np.ascontiguousarray(np.concatenate([B.reads_from_ref(ref, nr, L, 40 + L), B.reads_random(nr // 2, L, 41 + L),
+                                                     exact, mut, low]))
+        lens = np.full(len(batch), L, np.int32)
+        lens[::5] = rng.integers(0, L + 1, len(lens[::5]))
+        for algo, min_len, use_lens in (("bwa", 1, False), ("bwa", 19, True), ("lut", 1, True), ("rmi", 1, False)):
+            ix = _index_for(pkg, ds, algo)
+            ll = lens if use_lens else None
+            offsets, smems, st = ix.find_smems(algo, batch, lens=ll, min_len=min_len)
+            rows = _rows_per_read(offsets, smems)
+            counts, out = o.find_smems_batch(algo, batch, lens=ll, min_len=min_len, nthreads=8)
+            st = st.cpu().numpy()
+            for r in range(len(batch)):
+                if counts[r] < 0:
+                    assert st[r] != 0, (L, algo, r)
+                else:
+                    assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (L, algo, min_len, r)
+    # a batch large enough for the 8-lanes-per-read form of the traversal (the batches above use 16)
+    big = np.ascontiguousarray(np.concatenate([B.reads_from_ref(ref, 50000, 270, 77), B.reads_random(16000, 270, 78)]))
+    big[:40, :260] = np.stack([ref[s0:s0 + 260] for s0 in rng.integers(0, n - 260, 40)])
+    lens = np.full(len(big), 270, np.int32)
+    lens[::7] = rng.integers(0, 271, len(lens[::7]))
+    for algo, min_len in (("bwa", 12), ("lut", 1)):
+        offsets, smems, st = _index_for(pkg, ds, algo).find_smems(algo, big, lens=lens, min_len=min_len)
+        counts, out = o.find_smems_batch(algo, big, lens=lens, min_len=min_len, nthreads=8)
+        offs, flat, st = offsets.cpu().numpy(), smems.cpu().numpy(), st.cpu().numpy()
+        ok = counts >= 0
+        assert ((st == 0) == ok).all() and (np.diff(offs)[ok] == counts[ok]).all()
+        want = np.concatenate([out[r, :counts[r]] for r in np.nonzero(ok)[0]])
+        assert np.array_equal(flat[:offs[-1]], want)
+
+
+@pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
 def test_sampled_search_equals_full_search(pkg, oracle_mod, ds):
     """Default search (every 4th position looked up, the three between two of them only where their values
     differ) against GENIE_OPT_SEARCH_ALL (every position looked up) on from-ref, random, exact and ragged
