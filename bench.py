@@ -291,7 +291,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         shape = ix.workspace_shape(L)           # bytes per read of the hand-off rows
         # COMPULSORY HBM bytes per read: what a kernel must read and write (inputs + hand-offs + outputs)
-        search_bytes = L + 4 + shape["fwd_stride"] + 16 * shape["qp_recs"] + shape["mmax_bytes"]
+        search_bytes = L + 4 + shape["fwd_stride"] + 16 * shape["qp_recs"]
         step_bytes = L + 16.0 * S + 12            # reads in, (start, end, lo, hi) rows + offset + status out
         key = f"config{args.config}:{mode}:{n_reads}" + ("" if not offcfg else ":" + ",".join(offcfg))
         ctr = load_counters(key)

@@ -37,19 +37,6 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
-// wave max in 6 DPP steps (row_shr 1,2,4,8, row_bcast 15/31), result read from lane 63: no LDS crossbar
-__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
-{
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // ------------------------------------------------------------------ packed windows
 // 32 bases starting at base offset `pos`: base j of the window sits in bits [62-2j, 63-2j].
 __device__ __forceinline__ uint64_t funnel(uint64_t w0, uint64_t w1, int sh /* 0..62, even */)
@@ -650,7 +637,6 @@ struct Workspace {
     RefRec *qp;          // qp_recs records of 16 bytes per read
     int32_t *status;     // used when the caller passes no status array
     uint8_t *kj;         // N x kj_row emitted (start | end << shift) entries of 2 or 4 bytes
-    uint32_t *mmax;      // N: an upper bound of the longest match in the read (bounds K_B's bisection windows)
     int32_t *counts;     // used by the CSR entry point
     uint8_t *scan_tmp;   // scratch of the offsets scan (CSR entry point)
 };
@@ -662,8 +648,7 @@ inline int64_t workspace_bytes_for(int64_t N, int max_len)
     Geometry g;
     shape_for(max_len, &g);
     return ws_align(N * (int64_t)g.fwd_stride) + ws_align(N * (int64_t)g.qp_stride * 16) + ws_align(N * 4) +
-           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * 4) + ws_align(N * 4) +
-           ws_align(compact_tmp_bytes(N)) + 256;
+           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * 4) + ws_align(compact_tmp_bytes(N)) + 256;
 }
 
 inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geometry &g, Workspace *ws)
@@ -679,8 +664,6 @@ inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geomet
     p += ws_align(N * 4);
     ws->kj = p;
     p += ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2));
-    ws->mmax = reinterpret_cast<uint32_t *>(p);
-    p += ws_align(N * 4);
     ws->counts = reinterpret_cast<int32_t *>(p);
     p += ws_align(N * 4);
     ws->scan_tmp = p;
@@ -710,13 +693,13 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         auto km = match_table_long_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
-                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, ws.mmax, st,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
         auto km = match_table_kernel;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
-                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, ws.mmax, st,
+                           fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, st,
                            g.grp, std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_debug << 8);
     }
     HIP_TRY(hipGetLastError());
@@ -737,7 +720,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         const int lds_b = tb * g.fwd_lds;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
         hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
-                           fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, ws.mmax, cnt, ws.kj, g.kj_row, head, head_stride,
+                           fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, cnt, ws.kj, g.kj_row, head, head_stride,
                            csr.offsets ? g.kj_row : cap, st);
     }
     HIP_TRY(hipGetLastError());
@@ -819,7 +802,7 @@ void find_smems_workspace_rows(int32_t max_len, int32_t out[4])
     shape_for(max_len, &g);
     out[0] = g.fwd_stride;
     out[1] = g.qp_recs;
-    out[2] = 4;                      // the longest-match word
+    out[2] = 0;                      // (a longest-match word, until K_B bounded its searches by the previous SMEM)
     out[3] = g.kj_row * (g.wide ? 4 : 2);
 }
 

@@ -330,7 +330,7 @@ class GenieIndex:
         """Per-read rows of the find_smems workspace (bytes / counts), for traffic accounting."""
         out = (C.c_int32 * 4)()
         N.check(N.lib().genie_find_smems_workspace_rows(int(max_len), out), "genie_find_smems_workspace_rows")
-        return {"fwd_stride": out[0], "qp_recs": out[1], "mmax_bytes": out[2], "kj_row_bytes": out[3]}
+        return {"fwd_stride": out[0], "qp_recs": out[1], "kj_row_bytes": out[3]}
 
     def search_kernel_name(self, mode, max_len):
         buf = C.create_string_buffer(160)

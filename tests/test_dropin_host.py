@@ -158,9 +158,9 @@ def test_workspace_rows_and_index_create_ex_arguments():
     import ctypes as C
     import genie_smem_amd as pkg
     w = pkg.GenieIndex.workspace_shape(150)
-    assert w == {"fwd_stride": 160, "qp_recs": 6, "mmax_bytes": 4, "kj_row_bytes": 2 * 152}
+    assert w == {"fwd_stride": 160, "qp_recs": 6, "kj_row_bytes": 2 * 152}
     w = pkg.GenieIndex.workspace_shape(2000)
-    assert w["fwd_stride"] == 4000 and w["qp_recs"] == 63 and w["mmax_bytes"] == 4
+    assert w["fwd_stride"] == 4000 and w["qp_recs"] == 63
     lib = pkg._native.lib()
     assert lib.genie_find_smems_workspace_rows(-1, (C.c_int32 * 4)()) == -1
     codes = np.zeros(64, np.uint8)
