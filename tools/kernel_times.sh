@@ -7,6 +7,6 @@ for n in $SIZES; do
   python3 - <<PY
 import csv
 rows=[r for r in csv.DictReader(open("$O/kt_kernel_stats.csv")) if "genie" in r["Name"]]
-print("reads $n:", "; ".join("%s %.1f us"%(r["Name"].split("::")[-1][:22], float(r["AverageNs"])/1e3) for r in rows[:3]))
+print("reads $n:", "; ".join("%s %.1f us"%(r["Name"].replace("(anonymous namespace)::","").replace("void ","").split("(")[0].split("::")[-1][:28], float(r["AverageNs"])/1e3) for r in rows[:3]))
 PY
 done
