@@ -528,6 +528,52 @@ __global__ void __launch_bounds__(kScanBlock) compact_scan_sums(unsigned long lo
     if (threadIdx.x == 0) block_sums[nblocks] = carry;
 }
 
+// single block: exclusive scan of the traversal kernels' block sums in place (+ grand total at [nblocks]); eight
+// values per thread and pass, so that 10^5 .. 10^6 sums (10^7 .. 10^8 reads) stay a few tens of microseconds
+__global__ void __launch_bounds__(kScanBlock) scan_block_sums_kernel(unsigned long long *__restrict__ sums, long long nblocks)
+{
+    constexpr int kPer = 8;
+    __shared__ unsigned long long wave_total[kScanBlock / kWave];
+    __shared__ unsigned long long carry;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < nblocks; base += (long long)kScanBlock * kPer) {
+        const long long i0 = base + (long long)threadIdx.x * kPer;
+        unsigned long long v[kPer], mine = 0;
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            v[e] = i0 + e < nblocks ? sums[i0 + e] : 0ull;
+            mine += v[e];
+        }
+        unsigned long long inc = mine;                               // inclusive scan of `mine` over the wave ...
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned int lo = (unsigned)__shfl_up((int)(unsigned)inc, off, kWave);
+            const unsigned int hi = (unsigned)__shfl_up((int)(unsigned)(inc >> 32), off, kWave);
+            if (lane >= off) inc += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == kWave - 1) wave_total[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry, all = 0;                  // ... and over the block
+        for (int w = 0; w < kScanBlock / kWave; w++) {
+            const unsigned long long t = wave_total[w];
+            before += w < wave ? t : 0ull;
+            all += t;
+        }
+        unsigned long long run = before + inc - mine;
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            if (i0 + e < nblocks) sums[i0 + e] = run;
+            run += v[e];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nblocks] = carry;
+}
+
 __global__ void __launch_bounds__(kScanBlock) compact_scatter(const int32_t *__restrict__ counts,
                                                               const int4 *__restrict__ slots, long long N, int cap,
                                                               const unsigned long long *__restrict__ block_sums,
@@ -638,17 +684,20 @@ struct Workspace {
     int32_t *status;     // used when the caller passes no status array
     uint8_t *kj;         // N x kj_row emitted (start | end << shift) entries of 2 or 4 bytes
     int32_t *counts;     // used by the CSR entry point
-    uint8_t *scan_tmp;   // scratch of the offsets scan (CSR entry point)
+    uint8_t *scan_tmp;   // the traversal blocks' sums and their scan (CSR entry point)
 };
 
 inline int64_t ws_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+// block sums of the traversal kernels (CSR form): one 64-bit word per block; the smallest block holds 16 reads
+inline int64_t block_sums_bytes(int64_t N) { return (N / 16 + 3) * 8; }
 
 inline int64_t workspace_bytes_for(int64_t N, int max_len)
 {
     Geometry g;
     shape_for(max_len, &g);
     return ws_align(N * (int64_t)g.fwd_stride) + ws_align(N * (int64_t)g.qp_stride * 16) + ws_align(N * 4) +
-           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * 4) + ws_align(compact_tmp_bytes(N)) + 256;
+           ws_align(N * (int64_t)g.kj_row * (g.wide ? 4 : 2)) + ws_align(N * 4) + ws_align(block_sums_bytes(N)) + 256;
 }
 
 inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geometry &g, Workspace *ws)
@@ -709,24 +758,30 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     uint8_t *head = WIDE ? ws.kj : reinterpret_cast<uint8_t *>(ws.qp) + g.qp_recs * 16;
     const int head_stride = WIDE ? g.kj_row * 4 : g.qp_stride * 16;
     const int tb = 256;
+    int reads_per_block = tb;                // of the traversal kernel
+    unsigned long long *bsums = csr.offsets ? reinterpret_cast<unsigned long long *>(ws.scan_tmp) : nullptr;
     if (WIDE) {                              // 8 lanes per read; 16 when the batch is too small to fill the chip otherwise
         const int lanes = N >= kLongEightLaneReads ? 8 : 16;
         auto kl = lanes == 8 ? traverse_long_kernel<MODE, 8> : traverse_long_kernel<MODE, 16>;
         hipLaunchKernelGGL(kl, dim3((unsigned)((N + tb / lanes - 1) / (tb / lanes))), dim3(tb), 0, s, d_lens,
                            (long long)N, fixed_len, min_len, ws.fwd, g.fwd_stride, cnt, reinterpret_cast<uint32_t *>(ws.kj),
-                           g.kj_row, csr.offsets ? g.kj_row : cap, st);
+                           g.kj_row, csr.offsets ? g.kj_row : cap, st, bsums);
+        reads_per_block = tb / lanes;
     } else {                                 // one lane per read, rows staged in LDS
         auto kb = traverse_kernel<MODE>;
         const int lds_b = tb * g.fwd_lds;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
         hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
                            fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, cnt, ws.kj, g.kj_row, head, head_stride,
-                           csr.offsets ? g.kj_row : cap, st);
+                           csr.offsets ? g.kj_row : cap, st, bsums);
     }
     HIP_TRY(hipGetLastError());
-    if (csr.offsets) {                       // offsets = exclusive scan of the counts (no slots involved)
-        int rc = launch_compact(cnt, nullptr, N, g.kj_row, csr.offsets, nullptr, 0, ws.scan_tmp, s);
-        if (rc) return rc;
+    int block_shift = 0;
+    while ((1 << block_shift) < reads_per_block) block_shift++;
+    if (csr.offsets) {                       // scan of the traversal blocks' sums; K_C adds the in-block part
+        const long long nb = (N + reads_per_block - 1) / reads_per_block;
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanBlock), 0, s, bsums, nb);
+        HIP_TRY(hipGetLastError());
     }
     // K_C: intervals + final rows, 16 lanes per read (4 reads per wave pass), persistent blocks
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
@@ -736,10 +791,10 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     if (csr.offsets)
         hipLaunchKernelGGL((interval_kernel<true, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
                            ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(csr.rows), 0,
-                           reinterpret_cast<const long long *>(csr.offsets), (long long)csr.cap_rows);
+                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift);
     else
         hipLaunchKernelGGL((interval_kernel<false, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
-                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll);
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll, nullptr, nullptr, 0);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
