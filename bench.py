@@ -331,6 +331,13 @@ def main():
                     "l2_read_requests_per_read": req / n_reads,
                     "l2_read_GBps": req * 64 / (kern_ms_avg * 1e-3) / 1e9, "l2_peak_GBps": L2_PEAK_GBS,
                     "l2_frac": req * 64 / (kern_ms_avg * 1e-3) / 1e9 / L2_PEAK_GBS,
+                    # the same requests against the L2's REQUEST rate: 34.5 TB/s = 128 channels x one 128-byte line per
+                    # clock, and a request for a 64-byte sector occupies a channel slot like a whole line (derived from
+                    # the guide's figure under that assumption; reads + writes of the dominant kernel)
+                    "l2_request_slots": {
+                        "per_s": (req + dom.get("TCP_TCC_WRITE_REQ_sum", 0)) / (kern_ms_avg * 1e-3),
+                        "peak_per_s": L2_PEAK_GBS * 1e9 / 128,
+                        "frac": (req + dom.get("TCP_TCC_WRITE_REQ_sum", 0)) / (kern_ms_avg * 1e-3) / (L2_PEAK_GBS * 1e9 / 128)},
                     "valu_insts_per_read": dom.get("SQ_INSTS_VALU", 0) / n_reads,
                     "valu_issue_share": (dom.get("SQ_ACTIVE_INST_VALU", 0) * 4 / ctr.get("simds", 1024)) /
                                         (dom.get("GRBM_GUI_ACTIVE", 1) / ctr.get("xcds", 8)) if dom.get("GRBM_GUI_ACTIVE") else None,
