@@ -378,6 +378,44 @@ def test_long_exact_matches_and_low_complexity(pkg, oracle_mod, ds):
                     assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (L, algo, r)
 
 
+def test_first_run_start_whatever_the_bytes(pkg, oracle_mod):
+    """The traversal kernel marks run starts of fwd[] by comparing bytes of its row with their left neighbours;
+    position 0 has none.  Reads built so that fwd[0] = a and fwd[3] = 255 - a (a byte and its complement -- the
+    pair a careless sentinel for 'the byte before position 0' would take for equal) and other first-dword patterns,
+    against the CPU oracle."""
+    rng = np.random.default_rng(99)
+    n = 30_000
+    ref = rng.integers(0, 4, n).astype(np.uint8)
+    reads = []
+    q = 15_000
+    for a in (20, 40, 64, 100, 127):
+        p0 = 1000 + 300 * len(reads)
+        x = ref[p0:p0 + a].copy()
+        y = rng.integers(0, 4, 255 - 2 * a).astype(np.uint8)
+        y[0] = (ref[p0 + a] + 1) % 4                         # locus A stops matching after a bases
+        ref[q - 1] = (ref[p0 + 2] + 1) % 4                   # locus B cannot be entered from position 2
+        ref[q:q + a - 3] = x[3:]
+        ref[q + a - 3:q + a - 3 + len(y)] = y
+        rd = np.concatenate([x, y, rng.integers(0, 4, 255).astype(np.uint8)])[:255]
+        rd[255 - a] = (ref[q + a - 3 + len(y)] + 1) % 4      # ... and stops after position 255 - a
+        reads.append(rd)
+        q += 400
+    reads += [rng.integers(0, 4, 255).astype(np.uint8) for _ in range(59)]
+    batch = np.ascontiguousarray(np.stack(reads))
+    ix = pkg.GenieIndex.build(ref, 12).to("cuda")
+    o = oracle_mod.Oracle(ref, 12)
+    fwd0 = []
+    for algo in ("bwa", "lut"):
+        offsets, smems, st = ix.find_smems(algo, batch)
+        rows = _rows_per_read(offsets, smems)
+        counts, out = o.find_smems_batch(algo, batch, nthreads=8)
+        assert (st.cpu().numpy() == 0).all() and (counts > 0).all()
+        for r in range(len(batch)):
+            assert rows[r].tolist() == out[r, :counts[r]].tolist(), (algo, r)
+        fwd0 = [int(out[r, 0, 1]) for r in range(5)]
+    assert fwd0 == [20, 40, 64, 100, 127]                     # the construction did what it says: fwd[0] = a
+
+
 @pytest.mark.parametrize("ds", ["syn100k_K15", "big100k_K15"])
 def test_long_reads_vs_oracle(pkg, oracle_mod, ds):
     """Reads of 256 .. 8192 bases (the 16-lanes-per-read traversal, windows of 704 positions in the match
