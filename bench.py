@@ -11,7 +11,7 @@ rank processes its own batch of the config's shape).  Config 4 (BASELINE configs
 80 M-read batch cut into contiguous shards with parallel.shard_bounds, per-rank outputs stay rank-local.
 
 A "step" = one pass of the hot path over one batch: ONE genie_find_smems_csr call (match statistics, traversal,
-offsets scan, interval search writing the CSR rows) with the reads already resident in HBM.  Rank 0 prints ONE
+scan of the block sums, interval search writing the offsets and the CSR rows) with the reads already resident in HBM.  Rank 0 prints ONE
 JSON line (schema in the task contract) with `roofline` and `cpu_baseline`.
 
 What the roofline object says: the path moves few bytes and is bound by the rate of random
@@ -303,7 +303,7 @@ def main():
                 "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, longest "
                               "match, status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
                               "not by HBM (see `binding`)",
-                "step": {"kernels": "match statistics + traversal + offsets scan + interval search -> CSR rows",
+                "step": {"kernels": "match statistics + traversal + scan of the block sums + interval search -> offsets and CSR rows",
                          "ms_avg": path_ms_avg, "compulsory_bytes_per_read": step_bytes,
                          "achieved": step_bytes * n_reads / (path_ms_avg * 1e-3) / 1e9,
                          "frac": step_bytes * n_reads / (path_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
