@@ -619,6 +619,7 @@ std::string g_err;
 struct Geometry {
     int grid, block, lds;
     int grp;         // reads per wave iteration (long reads: 1)
+    int wps;         // waves per SIMD the match-statistics kernel is built for (match_table_kernel<WPS>)
     int wide;        // reads longer than 255 bases: uint16 fwd[], K_B reads it from global memory
     int max_len;
     int fwd_stride;  // bytes per fwd[] row in the workspace
@@ -667,7 +668,8 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     }
     if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
     g->block = wpb * kWave;
-    int bpc = std::min(lds_cap / g->lds, 32 / wpb);
+    g->wps = !g->wide && (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2 ? 6 : 8;
+    int bpc = std::min(lds_cap / g->lds, 4 * g->wps / wpb);                     // resident blocks per CU
     if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
     if (bpc < 1) bpc = 1;
     long long gr = (long long)cus * bpc;
@@ -745,7 +747,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
-        auto km = match_table_kernel;
+        auto km = g.wps == 6 ? match_table_kernel<6> : match_table_kernel<8>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, st,
@@ -841,9 +843,9 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
 // Name of the match-statistics kernel the plan picks (as rocprofv3 prints it, without the argument list).
 int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap)
 {
-    (void)ix;
     (void)mode;
-    const char *name = max_len > 255 ? "match_table_long_kernel" : "match_table_kernel";
+    const bool big = (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2;
+    const char *name = max_len > 255 ? "match_table_long_kernel" : (big ? "match_table_kernel<6>" : "match_table_kernel<8>");
     if (!buf || cap < (int)strlen(name) + 1) return GENIE_E_CAPACITY;
     memcpy(buf, name, strlen(name) + 1);
     return GENIE_OK;

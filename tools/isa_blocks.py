@@ -2,7 +2,7 @@
 """Static instruction mix per basic block of one kernel in a hipcc -S dump.
 
   hipcc --offload-arch=gfx950 ... --cuda-device-only -S -o kernels.s kernels.hip
-  python tools/isa_blocks.py kernels.s 'match_table_kernelILi1E' [--min 8]
+  python tools/isa_blocks.py kernels.s 'match_table_kernelILi8E' [--min 8]
 
 Prints, per label-delimited block: line range, VALU / SALU / LDS / VMEM / branch counts, and the source
 lines (from `; kernels.hip:NNN` style comments when -g was used) if present.  Loops show up as a block
