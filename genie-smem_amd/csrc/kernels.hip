@@ -668,7 +668,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     }
     if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
     g->block = wpb * kWave;
-    g->wps = !g->wide && (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2 ? 6 : 8;
+    g->wps = !g->wide && (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2 ? 4 : 8;
     int bpc = std::min(lds_cap / g->lds, 4 * g->wps / wpb);                     // resident blocks per CU
     if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
     if (bpc < 1) bpc = 1;
@@ -747,7 +747,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
-        auto km = g.wps == 6 ? match_table_kernel<6> : match_table_kernel<8>;
+        auto km = g.wps == 4 ? match_table_kernel<4> : match_table_kernel<8>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, st,
@@ -787,7 +787,9 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     }
     // K_C: intervals + final rows, 16 lanes per read (4 reads per wave pass), persistent blocks
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
-    long long grid_c = (long long)cus * (32 / kIvWaves);
+    // (a table beyond an XCD's L2: half the blocks -- fewer waves thrash the L2 less; 1 Mb reference 1.50 -> 1.40 ms per
+    // 4 x 10^6 reads, while the 100 kb reference wants them all: 0.18 -> 0.22 ms with half)
+    long long grid_c = (long long)cus * (g.wps == 8 ? 32 / kIvWaves : 16 / kIvWaves);
     const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
     if (csr.offsets)
@@ -845,7 +847,7 @@ int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, cha
 {
     (void)mode;
     const bool big = (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2;
-    const char *name = max_len > 255 ? "match_table_long_kernel" : (big ? "match_table_kernel<6>" : "match_table_kernel<8>");
+    const char *name = max_len > 255 ? "match_table_long_kernel" : (big ? "match_table_kernel<4>" : "match_table_kernel<8>");
     if (!buf || cap < (int)strlen(name) + 1) return GENIE_E_CAPACITY;
     memcpy(buf, name, strlen(name) + 1);
     return GENIE_OK;

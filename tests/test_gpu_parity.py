@@ -646,7 +646,7 @@ def test_absent_base_is_flagged(pkg):
 def test_report_helpers(pkg):
     """genie_search_kernel_name / genie_launch_info: what bench.py and the profile summaries key on."""
     ix = _index(pkg, "syn10k_K8")
-    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8>"     # the 6-wave build is for tables beyond an XCD's L2
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8>"     # the <4> build is for tables beyond an XCD's L2
     assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel"
     info = ix.launch_info("lut", 150)
     assert info["block"] == 512 and 0 < info["lds_bytes"] <= 160 * 1024 and info["grid"] > 0
@@ -768,7 +768,7 @@ def test_one_megabase_reference(pkg, oracle_mod):
     r = pkg.RMI_LUT([1000], 15, "REF_1M.fa", matcher=m)
     r.train_RMI()
     ix = r._index()
-    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<6>"     # 8 MB table: the three-blocks-per-CU build
+    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<4>"     # 8 MB table: the two-blocks-per-CU build
     o = oracle_mod.Oracle(ref, 15)
     coefs, icpts = r.rmi.coefficients()
     o.set_rmi([1000], coefs, icpts)
