@@ -183,11 +183,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; (a rehearsal of the N > 1 path on a box with fewer GPUs than ranks shares them)
+    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL over xGMI.  GENIE_BENCH_BACKEND=gloo is a REHEARSAL switch (two ranks on one GPU cannot form an RCCL
+        # communicator); the driver's runs use the default.
+        backend = os.environ.get("GENIE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     # ---- index: rank 0 builds, ONE broadcast of the image (RCCL over xGMI), no later traffic
     t_build = time.perf_counter()
