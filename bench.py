@@ -307,8 +307,8 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_read": search_bytes,
                 "kernel_ms_avg": kern_ms_avg, "kernel_ms_min": float(np.min(kern_ms)),
-                "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, longest "
-                              "match, status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
+                "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, "
+                              "status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
                               "not by HBM (see `binding`)",
                 "step": {"kernels": "match statistics + traversal + scan of the block sums + interval search -> offsets and CSR rows",
                          "ms_avg": path_ms_avg, "compulsory_bytes_per_read": step_bytes,
