@@ -787,9 +787,9 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     }
     // K_C: intervals + final rows, 16 lanes per read (4 reads per wave pass), persistent blocks
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
-    // (a table beyond an XCD's L2: half the blocks -- fewer waves thrash the L2 less; 1 Mb reference 1.50 -> 1.40 ms per
-    // 4 x 10^6 reads, while the 100 kb reference wants them all: 0.18 -> 0.22 ms with half)
-    long long grid_c = (long long)cus * (g.wps == 8 ? 32 / kIvWaves : 16 / kIvWaves);
+    // (half the blocks help on the 1 Mb reference, 1.50 -> 1.40 ms per 4 x 10^6 reads, but cost at 300 kb, 0.215 -> 0.250 ms
+    // per 10^6, with the same 8 MB table: not worth a rule)
+    long long grid_c = (long long)cus * (32 / kIvWaves);
     const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
     if (csr.offsets)
