@@ -61,6 +61,22 @@ CONFIGS = {
 }
 K = 15
 EXPERTS = [1000]
+GEN_CHUNK = 10_000_000                           # reads are generated (on the device) in pieces
+
+
+def shard_seed(cfg, world, rank):
+    """Seed of shard `rank` of `world` of a strong-scaling batch (BASELINE configs[4])."""
+    return cfg["read_seed"] + 1000 * world + rank
+
+
+def gen_reads(ref_dev, n, L, seed, piece, read_kind="fromref"):
+    """Piece `piece` (GEN_CHUNK reads at most) of a rank's batch, generated on the device that holds `ref_dev`
+    (uint8 tensor of the reference's codes): seconds instead of minutes of host time for 10^7 .. 10^8 reads."""
+    if read_kind == "random":
+        gen = torch.Generator(device=ref_dev.device)
+        gen.manual_seed(seed + 7919 * piece)
+        return torch.randint(0, 4, (n, L), generator=gen, device=ref_dev.device, dtype=torch.uint8)
+    return synth.reads_from_ref_device(ref_dev, n, L, seed + 7919 * piece)
 
 
 def build_index(cfg, device):
@@ -79,7 +95,7 @@ def cpu_baseline(ref, cfg, rl, mode, sample_reads):
     from oracle import oracle as orc
     orc.build()
     nproc = os.cpu_count() or 1
-    threads = max(1, min(nproc, 64))
+    threads = nproc                                  # all host cores (and one thread, below)
     o = orc.Oracle(ref, K)
     coefs, icpts = rl.rmi.coefficients()
     o.set_rmi(EXPERTS, coefs, icpts)
@@ -148,63 +164,28 @@ def load_counters(key):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default=None, choices=["bwa", "lut", "rmi"])
-    ap.add_argument("--reads", type=int, default=None, help="reads per step: per GPU (configs 1-3) or in all (config 4)")
-    ap.add_argument("--read-len", type=int, default=None, help="off-config read length (sweeps only; named in config.workload)")
-    ap.add_argument("--read-kind", default="fromref", choices=["fromref", "random"], help="off-config read distribution (sweeps only)")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-from-host", action="store_true")
-    ap.add_argument("--search-all", action="store_true", help="GENIE_OPT_SEARCH_ALL: look up every position, no sampling (A/B runs)")
-    args = ap.parse_args()
-
-    cfg = dict(CONFIGS[args.config])
-    offcfg = []
-    if args.read_len and args.read_len != cfg["L"]:
-        cfg["L"] = args.read_len
-        offcfg.append(f"read_len={args.read_len}")
-    if args.read_kind != "fromref":
-        offcfg.append(f"reads={args.read_kind}")
-    mode = args.mode or cfg["mode"]
-    if mode != cfg["mode"]:
-        offcfg.append(f"mode={mode}")
-    if args.search_all:
-        offcfg.append("search-all")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    # one rank per GPU; (a rehearsal of the N > 1 path on a box with fewer GPUs than ranks shares them)
-    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(device)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL over xGMI.  GENIE_BENCH_BACKEND=gloo is a REHEARSAL switch (two ranks on one GPU cannot form an RCCL
-        # communicator); the driver's runs use the default.
-        backend = os.environ.get("GENIE_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
+def run_workload(args, cfg_id, mode, steps, warmup, world, rank, device, total_reads=None, read_kind="fromref", read_len=None):
+    """Build (rank 0) and broadcast the index of BASELINE config `cfg_id`, generate this rank's batch, time `steps` calls of
+    the hot path after `warmup` untimed ones (barrier + synchronize on both sides, MAX over ranks).  Returns everything
+    the report needs."""
+    cfg = dict(CONFIGS[cfg_id])
+    if read_len:
+        cfg["L"] = read_len
     # ---- index: rank 0 builds, ONE broadcast of the image (RCCL over xGMI), no later traffic
     t_build = time.perf_counter()
     if rank == 0:
         ref, ix, rl = build_index(cfg, device)
     else:
         ref, ix, rl = None, None, None
-    if world > 1:
-        ix = parallel.broadcast_index(ix, src=0, device=device)
     t_build = time.perf_counter() - t_build
+    broadcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t_bc = time.perf_counter()
+        ix = parallel.broadcast_index(ix, src=0, device=device)
+        torch.cuda.synchronize(device)
+        broadcast_ms = (time.perf_counter() - t_bc) * 1e3
     if args.search_all:
         ix.set_option(g._native.OPT_SEARCH_ALL, 1)
 
@@ -212,25 +193,22 @@ def main():
     # contiguous shard of ONE batch (the shard is generated with the shard's own seed: shard s of W is the
     # same reads whichever rank holds it)
     ref_codes = synth.synth_ref(cfg["n"], cfg["ref_seed"])
-    total_reads = args.reads or cfg["reads"]
+    total_reads = total_reads or cfg["reads"]
     if cfg["scaling"] == "strong":
         lo, hi = parallel.shard_bounds(total_reads, rank, world)
-        n_reads, seed = hi - lo, cfg["read_seed"] + 1000 * world + rank
+        n_reads, seed = hi - lo, shard_seed(cfg, world, rank)
     else:
         n_reads, seed = total_reads, cfg["read_seed"] + rank
     L = cfg["L"]
-    gen_chunk = 10_000_000                       # generate on the host in pieces: 80 M reads are 12 GB
     reads = torch.empty((n_reads, L), dtype=torch.uint8, device=device)
-    for c0 in range(0, n_reads, gen_chunk):
-        c1 = min(n_reads, c0 + gen_chunk)
-        if args.read_kind == "random":
-            part = np.random.default_rng(seed + 7919 * (c0 // gen_chunk)).integers(0, 4, (c1 - c0, L)).astype(np.uint8)
-        else:
-            part = synth.reads_from_ref_fast(ref_codes, c1 - c0, L, seed + 7919 * (c0 // gen_chunk))
-        reads[c0:c1].copy_(torch.as_tensor(part))
+    ref_dev = torch.as_tensor(ref_codes).to(device)
+    for c0 in range(0, n_reads, GEN_CHUNK):
+        c1 = min(n_reads, c0 + GEN_CHUNK)
+        reads[c0:c1] = gen_reads(ref_dev, c1 - c0, L, seed, c0 // GEN_CHUNK, read_kind)
+    del ref_dev
     status = torch.empty(n_reads, dtype=torch.int32, device=device)
     offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=device)
-    rows_cap = n_reads * (max(40, L // 3) if args.read_kind == "random" else max(16, L // 9))    # >= 1.3x the mean count
+    rows_cap = n_reads * (max(40, L // 3) if read_kind == "random" else max(16, L // 9))    # >= 1.3x the mean count
     out = torch.empty((rows_cap, 4), dtype=torch.int32, device=device)
     lib = g._native.lib()
     ws_bytes = int(lib.genie_find_smems_workspace_bytes(n_reads, L))
@@ -247,8 +225,8 @@ def main():
         e = torch.cuda.Event(enable_timing=True)
         e.record(stream)                       # materialise the hipEvent_t handle
         return e
-    ev = [(mk(), mk()) for _ in range(args.steps)]
-    ev_k = [(mk(), mk()) for _ in range(args.steps)]
+    ev = [(mk(), mk()) for _ in range(steps)]
+    ev_k = [(mk(), mk()) for _ in range(steps)]
     torch.cuda.synchronize(device)
     EV = lambda e: C.c_void_p(e.cuda_event)                                      # noqa: E731
 
@@ -261,14 +239,14 @@ def main():
         if i is not None:
             ev[i][1].record(stream)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     torch.cuda.synchronize(device)
     if world > 1:
@@ -288,71 +266,142 @@ def main():
     tot = torch.tensor([n_reads, total], dtype=torch.float64, device=device)      # units all ranks processed
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    all_reads, all_rows = int(tot[0].item()), int(tot[1].item())
     kern_ms = [a.elapsed_time(b) for a, b in ev_k]
     path_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_ms_avg, path_ms_avg = float(np.mean(kern_ms)), float(np.mean(path_ms))
+    return dict(cfg=cfg, cfg_id=cfg_id, mode=mode, steps=steps, warmup=warmup, ix=ix, rl=rl, ref_codes=ref_codes, reads=reads,
+                n_reads=n_reads, L=L, dt=dt, total=total, all_reads=int(tot[0].item()), all_rows=int(tot[1].item()),
+                kern_ms=kern_ms, path_ms=path_ms, t_build=t_build, broadcast_ms=broadcast_ms, read_kind=read_kind,
+                image_bytes=int(ix.blob.numel()))
+
+
+def roofline_of(w, offcfg=()):
+    """The `roofline` object of one measured workload (module docstring)."""
+    cfg, ix, mode, L, n_reads = w["cfg"], w["ix"], w["mode"], w["L"], w["n_reads"]
+    kern_ms_avg, path_ms_avg = float(np.mean(w["kern_ms"])), float(np.mean(w["path_ms"]))
+    S = w["total"] / n_reads
+    ms_step = w["dt"] / w["steps"] * 1e3
+    shape = ix.workspace_shape(L)           # bytes per read of the hand-off rows
+    # COMPULSORY HBM bytes per read: what a kernel must read and write (inputs + hand-offs + outputs)
+    search_bytes = L + 4 + shape["fwd_stride"] + 16 * shape["qp_recs"]
+    step_bytes = L + 16.0 * S + 12            # reads in, (start, end, lo, hi) rows + offset + status out
+    key = f"config{w['cfg_id']}:{mode}:{n_reads}" + ("" if not offcfg else ":" + ",".join(offcfg))
+    ctr = load_counters(key)
+    kname = ix.search_kernel_name(mode, L)
+    achieved = search_bytes * n_reads / (kern_ms_avg * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_read": search_bytes,
+            "kernel_ms_avg": kern_ms_avg, "kernel_ms_min": float(np.min(w["kern_ms"])),
+            "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, "
+                          "status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
+                          "not by HBM (see `binding`)",
+            "step": {"kernels": "match statistics + traversal + scan of the block sums + interval search -> offsets and CSR rows",
+                     "ms_avg": path_ms_avg, "compulsory_bytes_per_read": step_bytes,
+                     "achieved": step_bytes * n_reads / (path_ms_avg * 1e-3) / 1e9,
+                     "frac": step_bytes * n_reads / (path_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "share_of_step": path_ms_avg / ms_step},
+            "survey_8d": {"alg_bytes_per_read": L + 16.0 * S + L * math.ceil(math.log2(cfg["n"] + 1)) * 12,
+                          "equiv_GBps": (L + 16.0 * S + L * math.ceil(math.log2(cfg["n"] + 1)) * 12) * n_reads / (path_ms_avg * 1e-3) / 1e9,
+                          "note": "SURVEY 8(d) prices a ceil(log2(n+1))-probe suffix-array search per position; the kernel "
+                                  "reads one 32-byte table entry per position instead, so this is an equivalent rate, not "
+                                  "a fraction of a roof"}}
+    if ctr:
+        ks = ctr["kernels"]
+        dom = ks.get(kname) or {}
+        roof["traffic"] = dom.get("hbm_bytes")
+        hbm_step = sum(k.get("hbm_bytes", 0.0) for k in ks.values())
+        roof["traffic_raw"] = dom.get("hbm_bytes_raw")
+        roof["counters_tag"] = ctr.get("tag")
+        roof["step"].update({"hbm_measured_bytes": hbm_step, "hbm_measured_bytes_raw": sum(k.get("hbm_bytes_raw", 0.0) for k in ks.values()),
+                             "hbm_note": "FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH HBM correction; an upper bound for narrow accesses); _raw = "
+                                         "FETCH_SIZE + WRITE_SIZE; both count table lines that miss L2 and hit the Infinity Cache", "hbm_measured_frac": hbm_step / (path_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic_ratio": hbm_step / (step_bytes * n_reads)})
+        if "TCP_TCC_READ_REQ_sum" in dom:
+            req = dom["TCP_TCC_READ_REQ_sum"]
+            roof["binding"] = {
+                "resource": "random L1->L2 read requests (one 64-byte line per table entry; about 64 in flight per CU at "
+                            "~220 cycles each) and VALU issue",
+                "l2_read_requests_per_read": req / n_reads,
+                "l2_read_GBps": req * 64 / (kern_ms_avg * 1e-3) / 1e9, "l2_peak_GBps": L2_PEAK_GBS,
+                "l2_frac": req * 64 / (kern_ms_avg * 1e-3) / 1e9 / L2_PEAK_GBS,
+                # the same requests against the L2's REQUEST rate: 34.5 TB/s = 128 channels x one 128-byte line per
+                # clock, and a request for a 64-byte sector occupies a channel slot like a whole line (derived from
+                # the guide's figure under that assumption; reads + writes of the dominant kernel)
+                "l2_request_slots": {
+                    "per_s": (req + dom.get("TCP_TCC_WRITE_REQ_sum", 0)) / (kern_ms_avg * 1e-3),
+                    "peak_per_s": L2_PEAK_GBS * 1e9 / 128,
+                    "frac": (req + dom.get("TCP_TCC_WRITE_REQ_sum", 0)) / (kern_ms_avg * 1e-3) / (L2_PEAK_GBS * 1e9 / 128)},
+                "valu_insts_per_read": dom.get("SQ_INSTS_VALU", 0) / n_reads,
+                "valu_issue_share": (dom.get("SQ_ACTIVE_INST_VALU", 0) * 4 / ctr.get("simds", 1024)) /
+                                    (dom.get("GRBM_GUI_ACTIVE", 1) / ctr.get("xcds", 8)) if dom.get("GRBM_GUI_ACTIVE") else None,
+                "wave_wait_share": dom.get("SQ_WAIT_ANY", 0) / dom["SQ_WAVE_CYCLES"] if dom.get("SQ_WAVE_CYCLES") else None,
+                "source": "profiles/pmc_counters.json"}
+    return roof, key, S, ms_step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default=None, choices=["bwa", "lut", "rmi"])
+    ap.add_argument("--reads", type=int, default=None, help="reads per step: per GPU (configs 1-3) or in all (config 4)")
+    ap.add_argument("--read-len", type=int, default=None, help="off-config read length (sweeps only; named in config.workload)")
+    ap.add_argument("--read-kind", default="fromref", choices=["fromref", "random"], help="off-config read distribution (sweeps only)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-from-host", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config 2 / config 3 records appended to the default line")
+    ap.add_argument("--search-all", action="store_true", help="GENIE_OPT_SEARCH_ALL: look up every position, no sampling (A/B runs)")
+    args = ap.parse_args()
+
+    cfg0 = CONFIGS[args.config]
+    offcfg = []
+    if args.read_len and args.read_len != cfg0["L"]:
+        offcfg.append(f"read_len={args.read_len}")
+    if args.read_kind != "fromref":
+        offcfg.append(f"reads={args.read_kind}")
+    mode = args.mode or cfg0["mode"]
+    if mode != cfg0["mode"]:
+        offcfg.append(f"mode={mode}")
+    if args.search_all:
+        offcfg.append("search-all")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    # one rank per GPU; (a rehearsal of the N > 1 path on a box with fewer GPUs than ranks shares them)
+    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(device)
+    backend = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL over xGMI.  GENIE_BENCH_BACKEND=gloo is a REHEARSAL switch (two ranks on one GPU cannot form an RCCL
+        # communicator); the driver's runs use the default.
+        backend = os.environ.get("GENIE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+    w = run_workload(args, args.config, mode, args.steps, args.warmup, world, rank, device, total_reads=args.reads,
+                     read_kind=args.read_kind, read_len=args.read_len)
+    cfg, ix, L, n_reads = w["cfg"], w["ix"], w["L"], w["n_reads"]
 
     if rank == 0:
-        S = total / n_reads
-        ms_step = dt / args.steps * 1e3
-        shape = ix.workspace_shape(L)           # bytes per read of the hand-off rows
-        # COMPULSORY HBM bytes per read: what a kernel must read and write (inputs + hand-offs + outputs)
-        search_bytes = L + 4 + shape["fwd_stride"] + 16 * shape["qp_recs"]
-        step_bytes = L + 16.0 * S + 12            # reads in, (start, end, lo, hi) rows + offset + status out
-        key = f"config{args.config}:{mode}:{n_reads}" + ("" if not offcfg else ":" + ",".join(offcfg))
-        ctr = load_counters(key)
-        kname = ix.search_kernel_name(mode, L)
-        achieved = search_bytes * n_reads / (kern_ms_avg * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_read": search_bytes,
-                "kernel_ms_avg": kern_ms_avg, "kernel_ms_min": float(np.min(kern_ms)),
-                "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, "
-                              "status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
-                              "not by HBM (see `binding`)",
-                "step": {"kernels": "match statistics + traversal + scan of the block sums + interval search -> offsets and CSR rows",
-                         "ms_avg": path_ms_avg, "compulsory_bytes_per_read": step_bytes,
-                         "achieved": step_bytes * n_reads / (path_ms_avg * 1e-3) / 1e9,
-                         "frac": step_bytes * n_reads / (path_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "share_of_step": path_ms_avg / ms_step},
-                "survey_8d": {"alg_bytes_per_read": L + 16.0 * S + L * math.ceil(math.log2(cfg["n"] + 1)) * 12,
-                              "equiv_GBps": (L + 16.0 * S + L * math.ceil(math.log2(cfg["n"] + 1)) * 12) * n_reads / (path_ms_avg * 1e-3) / 1e9,
-                              "note": "SURVEY 8(d) prices a ceil(log2(n+1))-probe suffix-array search per position; the kernel "
-                                      "reads one 32-byte table entry per position instead, so this is an equivalent rate, not "
-                                      "a fraction of a roof"}}
-        if ctr:
-            ks = ctr["kernels"]
-            dom = ks.get(kname) or {}
-            roof["traffic"] = dom.get("hbm_bytes")
-            hbm_step = sum(k.get("hbm_bytes", 0.0) for k in ks.values())
-            roof["traffic_raw"] = dom.get("hbm_bytes_raw")
-            roof["step"].update({"hbm_measured_bytes": hbm_step, "hbm_measured_bytes_raw": sum(k.get("hbm_bytes_raw", 0.0) for k in ks.values()),
-                                 "hbm_note": "FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH HBM correction; an upper bound for narrow accesses); _raw = "
-                                             "FETCH_SIZE + WRITE_SIZE; both count table lines that miss L2 and hit the Infinity Cache", "hbm_measured_frac": hbm_step / (path_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic_ratio": hbm_step / (step_bytes * n_reads)})
-            if "TCP_TCC_READ_REQ_sum" in dom:
-                req = dom["TCP_TCC_READ_REQ_sum"]
-                roof["binding"] = {
-                    "resource": "random L1->L2 read requests (one 64-byte line per table entry; about 64 in flight per CU at "
-                                "~220 cycles each) and VALU issue",
-                    "l2_read_requests_per_read": req / n_reads,
-                    "l2_read_GBps": req * 64 / (kern_ms_avg * 1e-3) / 1e9, "l2_peak_GBps": L2_PEAK_GBS,
-                    "l2_frac": req * 64 / (kern_ms_avg * 1e-3) / 1e9 / L2_PEAK_GBS,
-                    # the same requests against the L2's REQUEST rate: 34.5 TB/s = 128 channels x one 128-byte line per
-                    # clock, and a request for a 64-byte sector occupies a channel slot like a whole line (derived from
-                    # the guide's figure under that assumption; reads + writes of the dominant kernel)
-                    "l2_request_slots": {
-                        "per_s": (req + dom.get("TCP_TCC_WRITE_REQ_sum", 0)) / (kern_ms_avg * 1e-3),
-                        "peak_per_s": L2_PEAK_GBS * 1e9 / 128,
-                        "frac": (req + dom.get("TCP_TCC_WRITE_REQ_sum", 0)) / (kern_ms_avg * 1e-3) / (L2_PEAK_GBS * 1e9 / 128)},
-                    "valu_insts_per_read": dom.get("SQ_INSTS_VALU", 0) / n_reads,
-                    "valu_issue_share": (dom.get("SQ_ACTIVE_INST_VALU", 0) * 4 / ctr.get("simds", 1024)) /
-                                        (dom.get("GRBM_GUI_ACTIVE", 1) / ctr.get("xcds", 8)) if dom.get("GRBM_GUI_ACTIVE") else None,
-                    "wave_wait_share": dom.get("SQ_WAIT_ANY", 0) / dom["SQ_WAVE_CYCLES"] if dom.get("SQ_WAVE_CYCLES") else None,
-                    "source": "profiles/pmc_counters.json"}
+        roof, key, S, ms_step = roofline_of(w, offcfg)
+        par = {"parallelism": f"query-sharded x{world}, index replicated (one RCCL broadcast)"}
+        if world > 1:
+            # what the process group itself reports, so that the line proves N ranks took part
+            par.update({"backend": dist.get_backend(), "backend_requested": backend, "world_size": dist.get_world_size(),
+                        "broadcast_ms": round(w["broadcast_ms"], 3), "broadcast_bytes": w["image_bytes"],
+                        "devices_visible": torch.cuda.device_count()})
         line = {
             "metric": f"query-bases/sec SMEM discovery, {cfg['ref']} ref x {L}bp reads; bit-exact SMEM set",
-            "value": all_reads * L * args.steps / dt,
+            "value": w["all_reads"] * L * args.steps / w["dt"],
             "unit": "query-bases/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -364,21 +413,22 @@ def main():
             "dtype": "u8/int32 (2-bit packed bases, int32 SA rows; f64 only in the RMI predict)",
             "data": "synthetic",
             "config": {"workload": cfg["name"] + ("" if not offcfg else " [off-config: " + ", ".join(offcfg) + "]"),
-                       "reference_bases": cfg["n"], "reads_per_step_all_gpus": all_reads, "reads_per_gpu_per_step": n_reads,
+                       "reference_bases": cfg["n"], "reads_per_step_all_gpus": w["all_reads"], "reads_per_gpu_per_step": n_reads,
                        "read_len": L, "K": K, "mode": mode, "rmi_experts": EXPERTS,
                        "read_distribution": "from-ref segments U{1..30}" if args.read_kind == "fromref" else "uniform random",
-                       "parallelism": f"query-sharded x{world}, index replicated (one RCCL broadcast)",
-                       "smems_per_read": round(all_rows / all_reads, 3), "launch": ix.launch_info(mode, L), "counters_key": key,
-                       "index_build_plus_broadcast_s": round(t_build, 3)},
+                       **par,
+                       "smems_per_read": round(w["all_rows"] / w["all_reads"], 3), "launch": ix.launch_info(mode, L), "counters_key": key,
+                       "index_build_s": round(w["t_build"], 3), "index_image_bytes": w["image_bytes"]},
             "roofline": roof,
         }
+        lib = g._native.lib()
         if world == 1 and not args.no_from_host and n_reads <= 2_000_000:
-            v, ms = from_host_rate(lib, ix, mode_id, reads.cpu().pin_memory(), L, S)
+            v, ms = from_host_rate(lib, ix, g._native.MODES[mode], w["reads"].cpu().pin_memory(), L, S)
             line["value_from_host"] = {"value": v, "unit": "query-bases/s", "ms_per_step": ms,
                                        "what": "pinned host reads -> H2D -> call -> D2H of offsets + rows, double-buffered on two "
                                                "streams (SURVEY 8d's wording of the metric; host-link bound; never `value`)"}
         if not args.no_cpu_baseline and world == 1:
-            base, rd_s, cnt_s, rows_s = cpu_baseline(ref_codes, cfg, rl, mode, args.cpu_sample)
+            base, rd_s, cnt_s, rows_s = cpu_baseline(w["ref_codes"], cfg, w["rl"], mode, args.cpu_sample)
             line["cpu_baseline"] = base
             # parity check on the CPU sample: the same reads through the GPU path, rows compared one by one
             nchk = min(20000, len(rd_s))
@@ -388,6 +438,24 @@ def main():
             for r in range(nchk):
                 assert (s2[o2[r]:o2[r + 1]] == rows_s[r, :cnt_s[r]]).all(), f"GPU/oracle rows differ at sample read {r}"
             line["cpu_baseline"]["parity_check"] = f"{nchk} sample reads: GPU (start, end, lo, hi) rows == oracle rows"
+        # ---- the default (driver-run) line also carries BASELINE configs[2] and [3], measured in the same process with
+        # fewer steps: config 1 stays the headline `value`
+        if world == 1 and args.config == 1 and not offcfg and not args.reads and not args.no_other_configs:
+            del w
+            torch.cuda.empty_cache()
+            line["other_configs"] = []
+            for cid, st in ((2, 5), (3, 3)):
+                w2 = run_workload(args, cid, CONFIGS[cid]["mode"], st, 1, world, rank, device)
+                r2, key2, S2, ms2 = roofline_of(w2)
+                line["other_configs"].append({
+                    "config": CONFIGS[cid]["name"], "baseline_configs_index": cid, "mode": w2["mode"],
+                    "value": w2["all_reads"] * w2["L"] * st / w2["dt"], "unit": "query-bases/s", "steps": st, "warmup": 1,
+                    "ms_per_step": ms2, "reads_per_step": w2["n_reads"], "smems_per_read": round(S2, 3),
+                    "kernel": r2["kernel"], "kernel_ms_avg": r2["kernel_ms_avg"],
+                    "roofline": {k: r2.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw")},
+                    "counters_key": key2})
+                del w2
+                torch.cuda.empty_cache()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -15,6 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libgenie_smem.so")
 CSRC = os.path.join(_PKG, "csrc")
 
+ABI_VERSION = 2
 HEADER_BYTES = 512
 MAX_K = 16
 MAX_READ_LEN = 8192
@@ -116,8 +117,9 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.genie_abi_version() != 1:
-        raise RuntimeError("libgenie_smem.so: ABI version mismatch")
+    if L.genie_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libgenie_smem.so: ABI version {L.genie_abi_version()}, this binding is for {ABI_VERSION} "
+                           "(rebuild: make -C genie-smem_amd/csrc)")
     _lib = L
     return L
 

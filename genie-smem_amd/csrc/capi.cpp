@@ -53,7 +53,8 @@ int genie_index_create(const uint8_t *codes, int64_t n, int32_t K, int32_t dir_b
 int genie_index_create_ex(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t dir_bits,
                           int32_t table_bits, genie_index **out)
 {
-    if (table_bits != 0 && (table_bits < 2 || table_bits > 12)) return GENIE_E_INVALID;
+    const int32_t P = (dir_bits <= 0 || dir_bits > GENIE_MAX_DIR_BITS) ? GENIE_MAX_DIR_BITS : dir_bits;   // as build_host_index
+    if (table_bits != 0 && (table_bits <= P || table_bits > 12)) return GENIE_E_INVALID;
     return make_index(codes, n, sa_one_based, K, dir_bits, table_bits, out);
 }
 
@@ -366,6 +367,7 @@ const char *genie_strerror(int status)
     case GENIE_E_BAD_BLOB: return "not a serialized GENIE index";
     case GENIE_E_NO_LUT: return "index built without a K-mer table (K = 0)";
     case GENIE_E_CAPACITY: return "output capacity too small";
+    case GENIE_W_SEARCH_ONLY: return "GENIE_OPT_SEARCH_ONLY is set: no outputs were produced";
     default: return "unknown status";
     }
 }

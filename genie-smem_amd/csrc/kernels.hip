@@ -58,10 +58,8 @@ __device__ __forceinline__ uint64_t rwin(const RefRec *ref, int pos)
 
 // Where a packed query lives.  QWords: 8-byte words (LDS scratch of the wave that packed it).
 // QRecs: the 16-byte overlapping records {w[i], w[i+1]} that K_A writes to global memory for
-// K_B -- every 32-base window is ONE 16-byte ALIGNED load.  (Two adjacent 8-byte global loads
-// get merged by the compiler into a dwordx4 at an 8-byte-aligned address; on MI355X that form
-// returned wrong window words under load in the lane-per-read kernel -- found by the 1M-read
-// parity test -- so global windows are always fetched as aligned records.)
+// K_C -- every 32-base window is ONE 16-byte ALIGNED load (one vector-memory instruction per window instead of
+// two 8-byte loads; round 2 rebuilt the two-load form and found it correct on this hardware too).
 struct QWords {
     const uint64_t *p;
     __device__ __forceinline__ uint64_t win(int pos) const { return qwin(p, pos); }
@@ -755,7 +753,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     }
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
-    if (ix->opt_search_only) return GENIE_OK;        // GENIE_OPT_SEARCH_ONLY: timing experiments, workspace only
+    if (ix->opt_search_only) return GENIE_W_SEARCH_ONLY;   // timing experiments: no counts / offsets / rows were written
     // the head of a read's (count, pairs) row: behind its packed-read records (short reads) or the kj row itself
     uint8_t *head = WIDE ? ws.kj : reinterpret_cast<uint8_t *>(ws.qp) + g.qp_recs * 16;
     const int head_stride = WIDE ? g.kj_row * 4 : g.qp_stride * 16;

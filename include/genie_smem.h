@@ -17,7 +17,8 @@
  *   - suffix-array rows: n+1 rows, row 0 is the '$' suffix; intervals are 0-based inclusive
  *     [lo, hi] exactly as ExactMatch.exact_match_back_prop returns them (SMEM/ExactMatch.py:151);
  *     an absent pattern is (-1, -1) where the reference returns the int -1;
- *   - every function returns 0 (GENIE_OK) or a negative genie_status; none throws.
+ *   - every function returns 0 (GENIE_OK) or a negative genie_status; none throws.  (One positive code exists,
+ *     GENIE_W_SEARCH_ONLY, returned only while the timing knob GENIE_OPT_SEARCH_ONLY is set.)
  *   - an index handle is immutable once opened on a device: any number of concurrent calls on
  *     distinct streams may share it.
  */
@@ -30,10 +31,10 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 1
+#define GENIE_ABI_VERSION 2      /* 2: GENIE_W_SEARCH_ONLY, option codes renumbered since 1, workspace layout, image version */
 #define GENIE_HEADER_BYTES 512      /* fixed-size header at the start of a serialized index */
 #define GENIE_MAX_K 16              /* K-mer codes are 32-bit (2 bits per base) */
-#define GENIE_MAX_DIR_BITS 7        /* P: prefix directory has 4^P + 1 entries, staged in LDS */
+#define GENIE_MAX_DIR_BITS 7        /* P: prefix directory has 4^P + 1 entries (64 KB: genie_sa_interval stages it in LDS) */
 #define GENIE_MAX_READ_LEN 8192     /* per-read scratch lives in LDS */
 #define GENIE_MAX_RMI_LEVELS 4
 
@@ -48,7 +49,9 @@ typedef enum genie_status {
     GENIE_E_NO_MODEL = -7,     /* RMI mode requested but no model was set */
     GENIE_E_BAD_BLOB = -8,     /* serialized index: wrong magic / version / size */
     GENIE_E_NO_LUT = -9,       /* LUT mode requested but the index was built with K = 0 */
-    GENIE_E_CAPACITY = -10     /* output buffer too small (compaction) */
+    GENIE_E_CAPACITY = -10,    /* output buffer too small (compaction) */
+    GENIE_W_SEARCH_ONLY = 1    /* GENIE_OPT_SEARCH_ONLY is set: only the match-statistics kernel was launched;
+                                  counts / offsets / rows were NOT written */
 } genie_status;
 
 /* Per-read status written by genie_find_smems into d_status (0 = ok).  They mirror how the
@@ -99,7 +102,7 @@ int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *s
                                int32_t dir_bits, genie_index **out);
 
 /* genie_index_create / _from_sa (sa_one_based may be NULL) with the size of the per-P2-mer tables chosen by
- * the caller: table_bits = P2 in (dir_bits, 12], 0 = automatic (smallest P2 with 4^P2 >= n/4: measured best on MI355X at n = 100 kb and 1 Mb).  A tuning
+ * the caller: table_bits = P2 in (dir_bits, 12] (anything else but 0 is GENIE_E_INVALID), 0 = automatic (smallest P2 with 4^P2 >= n/4: measured best on MI355X at n = 100 kb and 1 Mb).  A tuning
  * knob of the index image only: results do not depend on it. */
 int genie_index_create_ex(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t dir_bits,
                           int32_t table_bits, genie_index **out);
@@ -225,8 +228,8 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  *   values differ.  Value 1 looks up every position (differential testing, A/B timing).
  * GENIE_OPT_GROUP_POSITIONS (default 0 = built-in): read positions a wave works on per iteration (tuning).
  * GENIE_OPT_SEARCH_BLOCKS_PER_CU (default 0 = as many as fit): cap on resident blocks of that kernel (tuning).
- * GENIE_OPT_SEARCH_ONLY (default 0): launch the match-statistics kernel only -- outputs are NOT produced; for
- *   timing that kernel alone.
+ * GENIE_OPT_SEARCH_ONLY (default 0): launch the match-statistics kernel only -- outputs are NOT produced and the
+ *   find_smems entry points return GENIE_W_SEARCH_ONLY instead of GENIE_OK; for timing that kernel alone.
  * GENIE_OPT_SEARCH_STAGES_OFF (default 0; honoured only while GENIE_OPT_SEARCH_ONLY is set, so never on a run that
  *   produces output): bit mask of stages of that kernel to skip -- 1 slow list, 2 round 2, 4 rounds 1+2, 8 packed-read
  *   records, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh). */

@@ -167,5 +167,7 @@ def test_workspace_rows_and_index_create_ex_arguments():
     h = C.c_void_p()
     u8p = C.POINTER(C.c_uint8)
     assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 7, 13, C.byref(h)) == -1      # table_bits out of range
+    assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 7, 7, C.byref(h)) == -1       # ... not above dir_bits
+    assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 0, 5, C.byref(h)) == -1       # (dir_bits 0 = 7)
     assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 7, 9, C.byref(h)) == 0
     lib.genie_index_destroy(h)

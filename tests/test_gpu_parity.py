@@ -912,3 +912,52 @@ def test_sharded_run_equals_unsharded(pkg, oracle_mod):
                 sts.append(s_)
             offs.append(torch.tensor([base], dtype=off0.dtype, device=off0.device))
             assert torch.equal(torch.cat(offs), off0) and torch.equal(torch.cat(rows), rows0) and torch.equal(torch.cat(sts), st0), (algo, W)
+
+
+def test_config4_eighty_million_reads_in_eight_shards(pkg, oracle_mod):
+    """BASELINE configs[4] at FULL size on one GPU: the 80 M x 150 bp batch on the 1 Mb reference (natively trained RMI
+    [1000]) cut into the W = 8 contiguous shards of parallel.shard_bounds and run one after the other, each shard generated
+    exactly as rank r of `bench.py --config 4 --gpus 8` generates it (bench.shard_seed / bench.gen_reads).  Per shard:
+    RMI and LUT runs bit-equal, no read flagged, every cover monotone and ending at the read end, intervals inside the
+    suffix array, and a 20 000-read slice (its position moving through the shard) row by row against the CPU oracle.
+    Reads are independent units (SMEM/SMEM.py:20,206,456), so the eight rank-local outputs ARE the result."""
+    import torch
+    import bench
+    from genie_smem_amd import parallel
+    cfg = bench.CONFIGS[4]
+    assert cfg["reads"] == 80_000_000 and cfg["n"] == 1_000_000 and cfg["L"] == 150 and cfg["scaling"] == "strong"
+    ref, ix, o = _index_1mb(pkg, oracle_mod)
+    ref_dev = torch.as_tensor(ref).cuda()
+    W, L, total_reads, total_rows = 8, cfg["L"], 0, 0
+    for rank in range(W):
+        lo, hi = parallel.shard_bounds(cfg["reads"], rank, W)
+        n = hi - lo
+        rd = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+        for c0 in range(0, n, bench.GEN_CHUNK):
+            c1 = min(n, c0 + bench.GEN_CHUNK)
+            rd[c0:c1] = bench.gen_reads(ref_dev, c1 - c0, L, bench.shard_seed(cfg, W, rank), c0 // bench.GEN_CHUNK)
+        off, rows, st = ix.find_smems("rmi", rd, rows_hint=n * 16)
+        assert int(st.abs().sum().item()) == 0
+        off2, rows2, st2 = ix.find_smems("lut", rd, rows_hint=n * 16)
+        assert torch.equal(off, off2) and torch.equal(rows, rows2) and torch.equal(st, st2), rank
+        del off2, rows2, st2
+        start, end, rlo, rhi = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+        assert bool(((start >= 0) & (start < end) & (end <= L) & (rlo >= 0) & (rlo <= rhi) & (rhi <= ix.n)).all())
+        assert bool((end[off[1:] - 1] == L).all())                   # the last SMEM of every read ends at the read end
+        inside = torch.ones(len(end) - 1, dtype=torch.bool, device=end.device)
+        inside[off[1:-1] - 1] = False
+        assert bool((end[1:][inside] > end[:-1][inside]).all())      # ends strictly increase inside a read
+        del inside
+        a = (n - 20_000) * rank // (W - 1)                           # oracle slice: start .. end of the shard as rank grows
+        offc = off[a:a + 20_001].cpu().numpy()
+        sm = rows[offc[0]:offc[-1]].cpu().numpy()
+        counts, want = o.find_smems_batch("rmi", rd[a:a + 20_000].cpu().numpy(), nthreads=16)
+        assert (np.diff(offc) == counts).all(), rank
+        rr = np.repeat(np.arange(20_000), counts)
+        tt = np.arange(len(rr)) - np.repeat(offc[:-1] - offc[0], counts)
+        assert (want[rr, tt] == sm).all(), rank
+        total_reads += n
+        total_rows += int(off[-1].item())
+        del rd, off, rows, st
+        torch.cuda.empty_cache()
+    assert total_reads == 80_000_000 and 8 * total_reads < total_rows < 16 * total_reads

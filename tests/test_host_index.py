@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg._native.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.genie_abi_version() == 1
+    assert lib.genie_abi_version() == pkg._native.ABI_VERSION == 2
     assert lib.genie_strerror(-7) == b"no RMI model installed"
 
 

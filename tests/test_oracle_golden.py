@@ -166,43 +166,3 @@ def test_rmi_predict_and_last_mile(oracle_mod, ds):
                 assert rc == 0 and (lo, hi) == tuple(lohi[i]), (tag, i, rc, lo, hi, lohi[i])
             else:
                 assert rc != 0, (tag, i)
-
-
-def test_lut_traversal_equals_bwa_traversal():
-    """The device runs ONE traversal for the three modes: SMEM.get_smems_lut / get_smems_rmi
-    (SMEM/SMEM.py:20-384) emit the same ordered SMEMs as SMEM.get_SMEMS with min_len = 1 (SMEM/SMEM.py:456-484).  Here
-    the oracle -- which keeps the reference's K-frame state machine literally and is pinned to its per-step traces --
-    is searched for a counter-example on adversarial inputs: tiny references over 2..4 letters with tandem repeats,
-    K = 2..8, stitched and random reads (tools/experiments/lut_vs_bwa_search.py ran the same search over 26 M reads)."""
-    from oracle import oracle as orc
-    import time
-    rng = np.random.default_rng(2024)
-    t0, total = time.time(), 0
-    while time.time() - t0 < 12:
-        n = int(rng.integers(20, 300))
-        sigma = int(rng.choice([2, 3, 4]))
-        ref = rng.integers(0, sigma, n).astype(np.uint8)
-        if rng.random() < 0.3:
-            unit = rng.integers(0, sigma, int(rng.integers(1, 7))).astype(np.uint8)
-            ref = np.concatenate([ref[:n // 3], np.tile(unit, int(rng.integers(3, 30))), ref[n // 3:]]).astype(np.uint8)
-        K = int(rng.integers(2, 9))
-        if len(set(ref.tolist())) < 2 or len(ref) < K + 2:
-            continue
-        o = orc.Oracle(ref, K)
-        L = int(rng.integers(K, 80))
-        rd = rng.integers(0, sigma, (200, L)).astype(np.uint8)
-        for r in range(0, 200, 2):
-            buf = []
-            while sum(len(b) for b in buf) < L:
-                p = int(rng.integers(0, len(ref)))
-                buf.append(ref[p:p + int(rng.integers(1, 25))])
-            rd[r] = np.concatenate(buf)[:L]
-        ca, ra = o.find_smems_batch("bwa", rd, nthreads=4)
-        cl, rl = o.find_smems_batch("lut", rd, nthreads=4)
-        for r in range(200):
-            if ca[r] < 0 or cl[r] < 0:
-                assert ca[r] < 0 and cl[r] < 0                # a base that never occurs: both refuse the read
-                continue
-            total += 1
-            assert ca[r] == cl[r] and (ra[r, :ca[r]] == rl[r, :cl[r]]).all(), (ref.tolist(), K, rd[r].tolist())
-    assert total > 20_000

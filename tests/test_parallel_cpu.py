@@ -43,9 +43,9 @@ def _worker(rank, world, port, q):
         q.put((rank, buf.numel(), digest, info["n"], info["K"], info["has_host"], lo, hi, bytes(hdr[:8].numpy())))
         with pytest.raises(RuntimeError):
             ix2.sa_interval(np.zeros((1, 4), np.uint8))          # no GPU -> loud failure, never a CPU path
-    finally:
         dist.barrier()
-        dist.destroy_process_group()
+    finally:
+        dist.destroy_process_group()                             # (no barrier here: a rank that failed must not hold the other)
 
 
 def test_broadcast_and_shards_world2():
@@ -55,10 +55,15 @@ def test_broadcast_and_shards_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=180) for _ in range(world))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        out = sorted(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                                          # a rank that died must not leave its peer waiting
+            if p.is_alive():
+                p.terminate()
     (r0, n0, d0, nn0, k0, host0, lo0, hi0, m0), (r1, n1, d1, nn1, k1, host1, lo1, hi1, m1) = out
     assert (n0, d0, nn0, k0, m0) == (n1, d1, nn1, k1, m1) and nn0 == 5000 and k0 == 8
     assert m0 == (0x58444947454E4547).to_bytes(8, "little")
@@ -75,3 +80,23 @@ def test_shard_bounds_tile_the_batch():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             assert max(hi - lo for lo, hi in cuts) <= (n + w - 1) // w
+
+
+def test_device_read_generator_on_cpu():
+    """synth.reads_from_ref_device (what bench.py and the config-4 test generate their batches with), run on the CPU
+    device: seeded, every read made of reference segments like the host generators' reads."""
+    import torch
+    from genie_smem_amd import synth
+    ref = synth.synth_ref(20_000, 7)
+    a = synth.reads_from_ref_device(ref, 3000, 150, 1005, device="cpu", chunk=1024)
+    b = synth.reads_from_ref_device(torch.as_tensor(ref), 3000, 150, 1005, device="cpu", chunk=1024)
+    assert a.dtype == torch.uint8 and tuple(a.shape) == (3000, 150) and torch.equal(a, b)
+    assert not torch.equal(a, synth.reads_from_ref_device(ref, 3000, 150, 1006, device="cpu"))
+    kmers = {ref[i:i + 12].tobytes() for i in range(len(ref) - 11)}
+
+    def share(reads):                       # 12-mers of the reads that occur in the reference
+        reads = np.asarray(reads)
+        return np.mean([reads[r, i:i + 12].tobytes() in kmers for r in range(200) for i in range(0, 139, 3)])
+    want = share(synth.reads_from_ref(ref, 200, 150, 5))
+    assert abs(share(a.numpy()) - want) < 0.05 and want > 0.3
+    assert share(synth.reads_random(200, 150, 5)) < 0.02

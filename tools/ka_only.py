@@ -26,6 +26,6 @@ P = lambda t: C.c_void_p(t.data_ptr())
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(int(os.environ.get("ITERS", 8))):
     rc = lib.genie_find_smems_csr(ix._h, g._native.MODES[mode], P(reads), None, N, L, L, 1, P(offsets), P(out), out.shape[0], P(status), P(ws), wsb, sp)
-    assert rc == 0, rc
+    assert rc in (0, 1), rc            # 1 = GENIE_W_SEARCH_ONLY
 torch.cuda.synchronize()
 print("ok")
