@@ -21,6 +21,7 @@ MAX_K = 16
 MAX_READ_LEN = 8192
 MODE_BWA, MODE_LUT, MODE_RMI = 0, 1, 2
 MODES = {"bwa": MODE_BWA, "lut": MODE_LUT, "rmi": MODE_RMI}
+TABLE_WIDE, TABLE_COMPACT = 1 << 8, 2 << 8        # genie_index_create_ex: ORed into table_bits
 OPT_SEARCH_ALL = 2
 OPT_GROUP_POSITIONS = 4
 OPT_SEARCH_ONLY = 5

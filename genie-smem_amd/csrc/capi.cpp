@@ -24,11 +24,11 @@ int query_cus(int device)
     return cus;
 }
 
-int make_index(const uint8_t *codes, int64_t n, const int32_t *sa1, int32_t K, int32_t P, int32_t P2, genie_index **out)
+int make_index(const uint8_t *codes, int64_t n, const int32_t *sa1, int32_t K, int32_t P, int32_t P2, int32_t fmt, genie_index **out)
 {
     if (!out) return GENIE_E_INVALID;
     HostIndex *h = nullptr;
-    int rc = build_host_index(codes, n, sa1, K, P, P2, &h);
+    int rc = build_host_index(codes, n, sa1, K, P, P2, fmt, &h);
     if (rc) return rc;
     genie_index *ix = new (std::nothrow) genie_index();
     if (!ix) { delete h; return GENIE_E_NOMEM; }
@@ -47,22 +47,25 @@ int genie_abi_version(void) { return GENIE_ABI_VERSION; }
 
 int genie_index_create(const uint8_t *codes, int64_t n, int32_t K, int32_t dir_bits, genie_index **out)
 {
-    return make_index(codes, n, nullptr, K, dir_bits, 0, out);
+    return make_index(codes, n, nullptr, K, dir_bits, 0, 0, out);
 }
 
 int genie_index_create_ex(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t dir_bits,
                           int32_t table_bits, genie_index **out)
 {
     const int32_t P = (dir_bits <= 0 || dir_bits > GENIE_MAX_DIR_BITS) ? GENIE_MAX_DIR_BITS : dir_bits;   // as build_host_index
+    const int32_t fmt = table_bits >> 8;                      // GENIE_TABLE_WIDE / GENIE_TABLE_COMPACT, 0 = automatic
+    table_bits &= 0xFF;
+    if (fmt < 0 || fmt > 2) return GENIE_E_INVALID;
     if (table_bits != 0 && (table_bits <= P || table_bits > 12)) return GENIE_E_INVALID;
-    return make_index(codes, n, sa_one_based, K, dir_bits, table_bits, out);
+    return make_index(codes, n, sa_one_based, K, dir_bits, table_bits, fmt, out);
 }
 
 int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K,
                                int32_t dir_bits, genie_index **out)
 {
     if (!sa_one_based) return GENIE_E_INVALID;
-    return make_index(codes, n, sa_one_based, K, dir_bits, 0, out);
+    return make_index(codes, n, sa_one_based, K, dir_bits, 0, 0, out);
 }
 
 int genie_index_set_rmi(genie_index *ix, int32_t nlev, const int32_t *sizes, const int32_t *scales,

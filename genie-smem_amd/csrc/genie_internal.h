@@ -14,7 +14,7 @@ struct uint2 { unsigned int x, y; };
 namespace genie {
 
 constexpr uint64_t kMagic = 0x58444947454e4547ull;  // "GENEGIDX"
-constexpr uint32_t kBlobVersion = 8;
+constexpr uint32_t kBlobVersion = 9;
 constexpr uint32_t kNoTail = 0xFFFFFFFFu;
 constexpr int kSectionAlign = 256;
 
@@ -64,6 +64,41 @@ struct MatchRec {
     uint32_t key[kMatchKeys];
 };
 static_assert(sizeof(MatchRec) == 32, "MatchRec must be one 32-byte fetch");
+
+// COMPACT match-table entry (16 bytes), the form used when the 32-byte form would not fit an XCD's L2 (references of
+// more than ~260 kb): on such tables the match-statistics kernel is bound by its L2 MISSES (each one a trip through the
+// fabric), so the table is halved: keys hold the 8 bases that follow the P2-mer instead of 16.
+//   w0 bits  0..23  lb     suffix-array row of the first suffix that starts with the P2-mer (n < 2^24)
+//      bits 24..27  cnt4   0: the P2-mer does not occur; 1..6: that many suffixes, their keys in key[0..cnt4) (unused
+//                          slots repeat key[0]); 7 (kM16More): 7 .. 13 suffixes -- key[0..4] hold the first five,
+//                          key[5] is the index of a 16-byte overflow block with the keys of rows lb + 5 .. (unused slots
+//                          repeat its first key), and nib = the number of suffixes - 7
+//      bits 28..31  nib    cnt4 in 1..6: 0, or kM16General = the rows decide (a suffix of the entry has fewer than
+//                          P2 + 8 bases, so its key is zero padded; or more than 13 suffixes; or no overflow block
+//                          index left): the entry only proves P2 bases;  cnt4 == 0: the longest prefix of the P2-mer
+//                          (0 .. P2-1 bases) that occurs anywhere in the reference, and then lb .. (key[0] | key[1] << 16)
+//                          are the suffix-array rows of that prefix
+//   key[i]  the 8 bases that follow the first P2 bases of suffix-array row lb + i, packed like the reference (base j in
+//           bits [14-2j, 15-2j]); ascending.
+// A match that exhausts a key (P2 + 8 bases, more of the read left) is decided by the suffix-array rows whose keys
+// agree (inline 32-base key, then the packed reference).
+constexpr int kM16Keys = 6;
+constexpr uint32_t kM16More = 7;
+constexpr uint32_t kM16General = 8;
+constexpr int kM16OvKeys = 8;                                  // keys per overflow block
+constexpr int kM16MaxRows = kM16Keys - 1 + kM16OvKeys;         // 13: the most suffixes an entry + its block describe
+constexpr int64_t kM16MaxOv = 65536;                           // overflow blocks a 16-bit index reaches
+struct MatchRec16 {
+    uint32_t w0;
+    uint16_t key[kM16Keys];
+};
+static_assert(sizeof(MatchRec16) == 16, "MatchRec16 must be one 16-byte load");
+struct MatchOv16 {
+    uint16_t key[kM16OvKeys];
+};
+constexpr int64_t kM16MaxN = (int64_t)1 << 24;
+constexpr int32_t kFlagCompactTable = 2;       // BlobHeader.flags / DevIndex.flags: mtab holds MatchRec16 entries
+constexpr int64_t kTableFitsL2 = 4ll << 20;    // bytes of table an XCD's L2 keeps
 
 // One slot of the device K-mer hash table (the GPU form of the reference's `lut` dict,
 // SMEM/LUT.py:33-35): key -> inclusive SA interval.  Empty slot: lo < 0.
@@ -130,8 +165,10 @@ struct BlobHeader {
     int32_t flags;        // kFlagDir16: every directory entry is within 65535 rows of entry (x & ~15)
     int64_t off_rmi_err;  // int32 [rmi_err_entries]: per leaf model, max |int(prediction) - row| over the training keys
     int64_t rmi_err_entries;   // 0 = no error table (model installed from coefficients)
-    int64_t off_mtab;     // MatchRec [4^P2]
+    int64_t off_mtab;     // MatchRec [4^P2 + overflow entries], or MatchRec16 [4^P2] (flags & kFlagCompactTable)
     int64_t mtab_entries;
+    int64_t off_ov;       // MatchOv16 [ov_entries]: overflow blocks of the compact table
+    int64_t ov_entries;   // 0 for the 32-byte form, else >= 1
 };
 // The serialized header occupies GENIE_HEADER_BYTES; the struct is copied into its front.
 static_assert(sizeof(BlobHeader) <= GENIE_HEADER_BYTES, "header size");
@@ -145,7 +182,9 @@ struct DevIndex {
     const RmiModel *rmi;
     const HeadRec *dir2;   // second-level range table (global, L2-resident), or null
     const int32_t *rmi_err; // per-leaf error bounds of a natively trained RMI, or null
-    const MatchRec *mtab;  // match table, 4^P2 entries + overflow entries
+    const MatchRec *mtab;  // match table, 4^P2 entries + overflow entries (MatchRec16 entries when flags & kFlagCompactTable)
+    const MatchOv16 *ov;   // compact table: overflow blocks
+    int32_t ov_entries;
     int32_t mtab_entries;
     int32_t flags;
     int32_t n;
@@ -176,7 +215,9 @@ struct HostIndex {
     std::vector<uint32_t> dir;
     int32_t P2 = 0;
     std::vector<HeadRec> dir2;           // 4^P2 entries
-    std::vector<MatchRec> mtab;          // 4^P2 entries
+    std::vector<MatchRec> mtab;          // 4^P2 entries (+ overflow), 32-byte form
+    std::vector<MatchRec16> mtab16;      // 4^P2 entries, compact form (then mtab is empty)
+    std::vector<MatchOv16> ov;           // compact form: overflow blocks
     int32_t flags = 0;
     std::vector<uint32_t> lut_code;      // sorted distinct K-mers
     std::vector<int32_t> lut_lo, lut_hi;
@@ -190,8 +231,10 @@ struct HostIndex {
     std::vector<int32_t> rmi_err;        // per leaf model (native training only)
 };
 
+// table_format: 0 = automatic (compact when the 32-byte table exceeds kTableFitsL2 and n < kM16MaxN), 1 = 32-byte entries,
+// 2 = compact entries
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
-                     int32_t dir2_bits, HostIndex **out);
+                     int32_t dir2_bits, int32_t table_format, HostIndex **out);
 void fill_header(const HostIndex &h, BlobHeader *hdr);
 int serialize(const HostIndex &h, void *dst, int64_t cap);
 int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t bytes, DevIndex *out);

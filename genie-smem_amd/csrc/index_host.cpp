@@ -101,9 +101,10 @@ bool suffix_less(const uint8_t *codes, int64_t n, int64_t a, int64_t b)
 }  // namespace
 
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
-                     int32_t dir2_bits, HostIndex **out)
+                     int32_t dir2_bits, int32_t table_format, HostIndex **out)
 {
     if (!codes || !out || n < 1 || n > 0x7ffffff0ll || K < 0 || K > GENIE_MAX_K) return GENIE_E_INVALID;
+    if (table_format < 0 || table_format > 2 || (table_format == 2 && n >= kM16MaxN)) return GENIE_E_INVALID;
     if (P <= 0 || P > GENIE_MAX_DIR_BITS) P = GENIE_MAX_DIR_BITS;
     for (int64_t i = 0; i < n; i++)
         if (codes[i] > 3) return GENIE_E_ALPHABET;
@@ -183,10 +184,20 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
             if (dir2_bits > P && dir2_bits <= 12) P2 = dir2_bits;       // build-time tuning (genie_index_create_ex)
             h->P2 = P2;
             const int64_t nb2 = (int64_t)1 << (2 * P2);
+            // table form: the 32-byte entries while they fit an XCD's L2, else the compact ones (genie_internal.h)
+            const bool compact = table_format == 2 ||
+                                 (table_format == 0 && nb2 * (int64_t)sizeof(MatchRec) > kTableFitsL2 && n < kM16MaxN);
+            const int KB = compact ? 8 : 16;                            // bases per key
+            if (compact) h->flags |= kFlagCompactTable;
             h->dir2.assign((size_t)nb2, HeadRec{0, 0, 0});
-            h->mtab.assign((size_t)nb2, MatchRec{0, 0, {0, 0, 0, 0, 0, 0}});
-            std::vector<uint32_t> cnt((size_t)nb2, 0);
-            std::vector<uint8_t> cut((size_t)nb2, 0);                   // a suffix of the entry has fewer than P2 + 16 bases
+            if (compact) {
+                h->mtab16.assign((size_t)nb2, MatchRec16{0, {0, 0, 0, 0, 0, 0}});
+                h->ov.assign(1, MatchOv16{{0, 0, 0, 0, 0, 0, 0, 0}});       // block 0 is never referenced
+            } else {
+                h->mtab.assign((size_t)nb2, MatchRec{0, 0, {0, 0, 0, 0, 0, 0}});
+            }
+            std::vector<uint32_t> cnt((size_t)nb2, 0), first((size_t)nb2, 0), ovf(compact ? (size_t)nb2 : 0, 0);
+            std::vector<uint8_t> cut((size_t)nb2, 0);                   // a suffix of the entry has fewer than P2 + KB bases
             for (int64_t r = 0; r < rows; r++) {
                 const int64_t s = h->sa0[(size_t)r];
                 if (n - s < P2) continue;
@@ -196,24 +207,47 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                     e.lb = (uint32_t)r;
                     e.key = h->sarec[(size_t)r].key;
                     e.meta = (n - s < P + 32) ? kHeadShort : 0;
-                    h->mtab[(size_t)c].lb = (uint32_t)r;
+                    first[(size_t)c] = (uint32_t)r;
                 }
                 e.meta++;
                 cnt[(size_t)c]++;
-                if (n - s < P2 + 16) cut[(size_t)c] = 1;
+                if (n - s < P2 + KB) cut[(size_t)c] = 1;
             }
             // keys: up to kMatchKeys in the entry itself; kMatchKeys+1 .. kMatchChainRows rows: kMatchKeys-1 in the
-            // entry, its last slot = index of the overflow entries (8 keys each) appended behind the table
+            // entry, its last slot = index of the overflow entries (8 keys each) appended behind the table.
+            // Compact form: up to kM16Keys in the entry; 7 .. kM16MaxRows rows: five in the entry + an overflow block of eight.
             for (int64_t r = 0; r < rows; r++) {
                 const int64_t s = h->sa0[(size_t)r];
                 if (n - s < P2) continue;
                 const uint64_t c = code_at64(codes, s, P2);
-                const uint32_t rows_c = cnt[(size_t)c], k = (uint32_t)r - h->mtab[(size_t)c].lb;
+                const uint32_t rows_c = cnt[(size_t)c], k = (uint32_t)r - first[(size_t)c];
                 uint32_t key = 0;
-                for (int j = 0; j < 16; j++) {
+                for (int j = 0; j < KB; j++) {
                     const int64_t p = s + P2 + j;
-                    key |= (p < n ? (uint32_t)codes[p] : 0u) << (30 - 2 * j);
+                    key |= (p < n ? (uint32_t)codes[p] : 0u) << (2 * (KB - 1 - j));
                 }
+                if (compact) {
+                    MatchRec16 &m = h->mtab16[(size_t)c];
+                    const bool block = !cut[(size_t)c] && rows_c > (uint32_t)kM16Keys && rows_c <= (uint32_t)kM16MaxRows;
+                    if (k == 0) {
+                        for (int j = 0; j < kM16Keys; j++) m.key[j] = (uint16_t)key;                 // unused slots repeat key[0]
+                        ovf[(size_t)c] = 0;
+                        if (block && (int64_t)h->ov.size() < kM16MaxOv) ovf[(size_t)c] = (uint32_t)h->ov.size();
+                        if (ovf[(size_t)c]) h->ov.push_back(MatchOv16{{0, 0, 0, 0, 0, 0, 0, 0}});
+                    }
+                    if (ovf[(size_t)c]) {
+                        MatchOv16 &o = h->ov[ovf[(size_t)c]];
+                        if (k < (uint32_t)kM16Keys - 1) m.key[k] = (uint16_t)key;
+                        else {
+                            if (k == (uint32_t)kM16Keys - 1) for (int j = 0; j < kM16OvKeys; j++) o.key[j] = (uint16_t)key;
+                            o.key[k - (kM16Keys - 1)] = (uint16_t)key;
+                        }
+                    } else if (k < (uint32_t)kM16Keys) {
+                        m.key[k] = (uint16_t)key;
+                    }
+                    continue;
+                }
+                h->mtab[(size_t)c].lb = first[(size_t)c];
                 const bool chain = !cut[(size_t)c] && rows_c > (uint32_t)kMatchKeys && rows_c <= (uint32_t)kMatchChainRows;
                 if (!chain) {
                     if (k < (uint32_t)kMatchKeys) h->mtab[(size_t)c].key[k] = key;
@@ -252,18 +286,40 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                 }
             }
             for (int64_t c = 0; c < nb2; c++) {
-                MatchRec &m = h->mtab[(size_t)c];
                 const uint32_t k = cnt[(size_t)c];
+                // absent: the longest prefix that does occur, and (for the interval kernel) that prefix's rows
+                int t = 0;
+                uint32_t plb = 0, plast = 0;
                 if (k == 0) {
-                    // absent: the longest prefix that does occur, and (for the interval kernel) that prefix's rows
-                    int t = P2 - 1;
+                    t = P2 - 1;
                     while (t >= 1 && !tcnt[(size_t)t][(size_t)((uint64_t)c >> (2 * (P2 - t)))]) t--;
-                    m.meta = (uint32_t)t;                                // lmask = 0, flags = 0, rows = 0
                     if (t >= 1) {
                         const size_t x = (size_t)((uint64_t)c >> (2 * (P2 - t)));
-                        m.lb = tfirst[(size_t)t][x];
-                        m.key[0] = m.lb + tcnt[(size_t)t][x] - 1;        // last row (inclusive)
+                        plb = tfirst[(size_t)t][x];
+                        plast = plb + tcnt[(size_t)t][x] - 1;               // last row (inclusive)
                     }
+                }
+                if (compact) {
+                    MatchRec16 &m = h->mtab16[(size_t)c];
+                    if (k == 0) {
+                        m.w0 = plb | ((uint32_t)t << 28);
+                        m.key[0] = (uint16_t)(plast & 0xFFFFu);
+                        m.key[1] = (uint16_t)(plast >> 16);
+                    } else if (k <= (uint32_t)kM16Keys) {
+                        m.w0 = first[(size_t)c] | (k << 24) | ((cut[(size_t)c] ? kM16General : 0u) << 28);
+                    } else if (ovf[(size_t)c]) {                          // 7 .. 13 suffixes, none cut short: five keys + a block
+                        m.key[kM16Keys - 1] = (uint16_t)ovf[(size_t)c];
+                        m.w0 = first[(size_t)c] | (kM16More << 24) | ((k - 7u) << 28);
+                    } else {                                              // the rows decide
+                        m.w0 = first[(size_t)c] | ((uint32_t)kM16Keys << 24) | (kM16General << 28);
+                    }
+                    continue;
+                }
+                MatchRec &m = h->mtab[(size_t)c];
+                if (k == 0) {
+                    m.meta = (uint32_t)t;                                // lmask = 0, flags = 0, rows = 0
+                    m.lb = plb;
+                    m.key[0] = plast;
                 } else {
                     const bool chain = !cut[(size_t)c] && k > (uint32_t)kMatchKeys && k <= (uint32_t)kMatchChainRows;
                     for (uint32_t i = k; i < (uint32_t)kMatchKeys; i++) m.key[i] = m.key[0];
@@ -354,8 +410,12 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->rmi_err_entries = (int64_t)h.rmi_err.size();
     off = align_up(off + (int64_t)std::max<size_t>(h.rmi_err.size(), 1) * 4);
     hdr->off_mtab = off;
-    hdr->mtab_entries = (int64_t)h.mtab.size();
-    off = align_up(off + (int64_t)h.mtab.size() * (int64_t)sizeof(MatchRec));
+    const bool compact = (h.flags & kFlagCompactTable) != 0;
+    hdr->mtab_entries = compact ? (int64_t)h.mtab16.size() : (int64_t)h.mtab.size();
+    off = align_up(off + (compact ? (int64_t)h.mtab16.size() * (int64_t)sizeof(MatchRec16) : (int64_t)h.mtab.size() * (int64_t)sizeof(MatchRec)));
+    hdr->off_ov = off;
+    hdr->ov_entries = (int64_t)h.ov.size();
+    off = align_up(off + (int64_t)std::max<size_t>(h.ov.size(), 1) * (int64_t)sizeof(MatchOv16));
     hdr->total_bytes = off;
 }
 
@@ -510,7 +570,12 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
     if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * sizeof(HeadRec));
     if (!h.rmi_err.empty()) memcpy(p + hdr.off_rmi_err, h.rmi_err.data(), h.rmi_err.size() * 4);
-    memcpy(p + hdr.off_mtab, h.mtab.data(), h.mtab.size() * sizeof(MatchRec));
+    if (h.flags & kFlagCompactTable) {
+        memcpy(p + hdr.off_mtab, h.mtab16.data(), h.mtab16.size() * sizeof(MatchRec16));
+        memcpy(p + hdr.off_ov, h.ov.data(), h.ov.size() * sizeof(MatchOv16));
+    } else {
+        memcpy(p + hdr.off_mtab, h.mtab.data(), h.mtab.size() * sizeof(MatchRec));
+    }
     return GENIE_OK;
 }
 
@@ -531,8 +596,12 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     if (hdr.P < 1 || hdr.P > GENIE_MAX_DIR_BITS || hdr.n < 1 || hdr.n > 0x7ffffff0ll) return GENIE_E_BAD_BLOB;
     if (hdr.K < 0 || hdr.K > GENIE_MAX_K) return GENIE_E_BAD_BLOB;
     if (hdr.dir_entries != ((int64_t)1 << (2 * hdr.P)) + 1) return GENIE_E_BAD_BLOB;
+    const bool compact = (hdr.flags & kFlagCompactTable) != 0;
     if (hdr.P2 <= hdr.P || hdr.P2 > 12 || hdr.dir2_entries != ((int64_t)1 << (2 * hdr.P2)) ||
         hdr.mtab_entries < hdr.dir2_entries || hdr.mtab_entries > hdr.dir2_entries + hdr.n || hdr.mtab_entries > (1 << 26))
+        return GENIE_E_BAD_BLOB;
+    if (compact ? (hdr.mtab_entries != hdr.dir2_entries || hdr.n >= kM16MaxN || hdr.ov_entries < 1 || hdr.ov_entries > kM16MaxOv)
+                : hdr.ov_entries != 0)
         return GENIE_E_BAD_BLOB;
     if (hdr.ref_recs < (hdr.n + 31) / 32 + 3) return GENIE_E_BAD_BLOB;
     // every section inside the image (a truncated or corrupt image must not become a wild device pointer)
@@ -543,7 +612,8 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
         !section_ok(hdr, bytes, hdr.off_rmi, hdr.rmi_models, sizeof(RmiModel)) ||
         !section_ok(hdr, bytes, hdr.off_dir2, hdr.dir2_entries, sizeof(HeadRec)) ||
         !section_ok(hdr, bytes, hdr.off_rmi_err, hdr.rmi_err_entries, 4) ||
-        !section_ok(hdr, bytes, hdr.off_mtab, hdr.mtab_entries, sizeof(MatchRec)))
+        !section_ok(hdr, bytes, hdr.off_mtab, hdr.mtab_entries, compact ? sizeof(MatchRec16) : sizeof(MatchRec)) ||
+        !section_ok(hdr, bytes, hdr.off_ov, hdr.ov_entries, sizeof(MatchOv16)))
         return GENIE_E_BAD_BLOB;
     // the hash table needs an empty slot for every probe sequence to end
     if (hdr.lut_keys < 0 || hdr.lut_slots < hdr.lut_keys + 1 || hdr.lut_slots > 0xFFFFFFFFll) return GENIE_E_BAD_BLOB;
@@ -572,6 +642,8 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
     out->dir2 = (const HeadRec *)(p + hdr.off_dir2);
     out->mtab = (const MatchRec *)(p + hdr.off_mtab);
     out->mtab_entries = (int32_t)hdr.mtab_entries;
+    out->ov = (const MatchOv16 *)(p + hdr.off_ov);
+    out->ov_entries = (int32_t)hdr.ov_entries;
     out->P2 = hdr.P2;
     out->flags = hdr.flags;
     out->rmi_err = hdr.rmi_err_entries > 0 ? (const int32_t *)(p + hdr.off_rmi_err) : nullptr;

@@ -419,6 +419,26 @@ __device__ __forceinline__ bool load_and_pack(const uint8_t *src, int L, int Lma
     return !__any(bad);
 }
 
+typedef int mt_v4i __attribute__((ext_vector_type(4)));
+
+// Compact match table: the keys of rows lb + 5 .. of an entry of 7 .. 13 suffixes, from its overflow block `blk` (one
+// 16-byte load): the smallest key ^ xk16 seen, and a bit (row - lb) for each of the `nov` rows whose key agrees with xk16
+// under `km16`.
+__device__ __forceinline__ void mt_ov_scan(const __amdgpu_buffer_rsrc_t ov, uint32_t blk, int nov, uint32_t xk16, uint32_t km16,
+                                           uint32_t &xmin, uint32_t &mask)
+{
+    const mt_v4i v = __builtin_amdgcn_raw_buffer_load_b128(ov, (int)(blk << 4), 0, 0);
+    const uint32_t d[4] = {(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w};
+#pragma unroll
+    for (int i = 0; i < kM16OvKeys; i++) {
+        const uint32_t x = ((d[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) ^ xk16;
+        if (i < nov) {
+            xmin = min(xmin, x);
+            mask |= (x & km16) == 0 ? 1u << (kM16Keys - 1 + i) : 0u;
+        }
+    }
+}
+
 #include "short_read_kernel.inc"
 #include "match_table_kernel.inc"
 
@@ -614,6 +634,11 @@ std::string g_err;
         if (e_ != hipSuccess) { set_hip_error(#expr, (int)e_); return GENIE_E_HIP; } \
     } while (0)
 
+inline long long table_bytes(const genie_index *ix)
+{
+    return (long long)((ix->dev.flags & kFlagCompactTable) ? sizeof(MatchRec16) : sizeof(MatchRec)) * ix->dev.mtab_entries;
+}
+
 struct Geometry {
     int grid, block, lds;
     int grp;         // reads per wave iteration (long reads: 1)
@@ -666,7 +691,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     }
     if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
     g->block = wpb * kWave;
-    g->wps = !g->wide && (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2 ? 4 : 8;
+    g->wps = !g->wide && table_bytes(ix) > kTableFitsL2 ? 4 : 8;
     int bpc = std::min(lds_cap / g->lds, 4 * g->wps / wpb);                     // resident blocks per CU
     if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
     if (bpc < 1) bpc = 1;
@@ -736,16 +761,18 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
 {
     int32_t *st = d_status ? d_status : ws.status;
     int32_t *cnt = d_counts ? d_counts : ws.counts;
-    const long long mtab_bytes = (long long)sizeof(MatchRec) * ix->dev.mtab_entries;
+    const bool c16 = (ix->dev.flags & kFlagCompactTable) != 0;
+    const long long mtab_bytes = table_bytes(ix);
     if (ix->ev_search_begin) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_begin, s));
     if (WIDE) {
-        auto km = match_table_long_kernel;
+        auto km = c16 ? match_table_long_kernel<true> : match_table_long_kernel<false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
-        auto km = g.wps == 4 ? match_table_kernel<4> : match_table_kernel<8>;
+        auto km = c16 ? (g.wps == 4 ? match_table_kernel<4, true> : match_table_kernel<8, true>)
+                      : (g.wps == 4 ? match_table_kernel<4, false> : match_table_kernel<8, false>);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, st,
@@ -790,12 +817,14 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     long long grid_c = (long long)cus * (32 / kIvWaves);
     const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
+    auto kc = csr.offsets ? (c16 ? interval_kernel<true, WIDE, true> : interval_kernel<true, WIDE, false>)
+                          : (c16 ? interval_kernel<false, WIDE, true> : interval_kernel<false, WIDE, false>);
     if (csr.offsets)
-        hipLaunchKernelGGL((interval_kernel<true, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
+        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
                            ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(csr.rows), 0,
                            reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift);
     else
-        hipLaunchKernelGGL((interval_kernel<false, WIDE>), dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
+        hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
                            ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll, nullptr, nullptr, 0);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
@@ -844,8 +873,10 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
 int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap)
 {
     (void)mode;
-    const bool big = (long long)sizeof(MatchRec) * ix->dev.mtab_entries > kMtTableFitsL2;
-    const char *name = max_len > 255 ? "match_table_long_kernel" : (big ? "match_table_kernel<4>" : "match_table_kernel<8>");
+    const bool big = table_bytes(ix) > kTableFitsL2, c16 = (ix->dev.flags & kFlagCompactTable) != 0;
+    const char *name = max_len > 255 ? (c16 ? "match_table_long_kernel<true>" : "match_table_long_kernel<false>")
+                                     : (big ? (c16 ? "match_table_kernel<4, true>" : "match_table_kernel<4, false>")
+                                            : (c16 ? "match_table_kernel<8, true>" : "match_table_kernel<8, false>"));
     if (!buf || cap < (int)strlen(name) + 1) return GENIE_E_CAPACITY;
     memcpy(buf, name, strlen(name) + 1);
     return GENIE_OK;

@@ -39,10 +39,11 @@ class GenieIndex:
 
     # ------------------------------------------------------------------ construction (host)
     @classmethod
-    def build(cls, codes, K, dir_bits=7, sa_one_based=None, table_bits=0):
+    def build(cls, codes, K, dir_bits=7, sa_one_based=None, table_bits=0, table_format="auto"):
         """codes: uint8 array of base codes 0..3; K: LUT / RMI key size (0 = none);
         sa_one_based: adopt this suffix array (reference JSON convention) instead of building;
-        table_bits: P2 of the per-P2-mer tables (0 = automatic), a tuning knob only."""
+        table_bits: P2 of the per-P2-mer tables (0 = automatic); table_format: "auto" (compact entries once the 32-byte
+        table would exceed an XCD's L2), "wide" or "compact" -- tuning knobs of the index image only."""
         codes = np.ascontiguousarray(codes, np.uint8)
         self = cls()
         u8p = C.POINTER(C.c_uint8)
@@ -52,8 +53,9 @@ class GenieIndex:
             if sa.size != codes.size + 1:
                 raise ValueError("suffix array must have n+1 rows")
             sa_p = sa.ctypes.data_as(C.POINTER(C.c_int32))
+        fmt = {"auto": 0, "wide": N.TABLE_WIDE, "compact": N.TABLE_COMPACT}[table_format]
         rc = N.lib().genie_index_create_ex(codes.ctypes.data_as(u8p), codes.size, sa_p, int(K), int(dir_bits),
-                                           int(table_bits), C.byref(self._h))
+                                           int(table_bits) | fmt, C.byref(self._h))
         N.check(rc, "genie_index_create")
         return self
 

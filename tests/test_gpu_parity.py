@@ -539,23 +539,27 @@ def test_randomized_configurations(pkg, oracle_mod):
                         s0 = int(rng.integers(1, 31 if kind == 1 else 4 * L))
                         buf.append(ref[p0:p0 + s0])
                     reads[r] = np.concatenate(buf)[:L]
-            ix = pkg.GenieIndex.build(ref, K)
-            coefs, icpts, _, _, _ = ix.train_rmi([10])
-            ix = ix.to("cuda")
             o = oracle_mod.Oracle(ref, K)
-            o.set_rmi([10], coefs, icpts)
-            for algo in ("bwa", "lut", "rmi"):
-                offsets, smems, st = ix.find_smems(algo, reads)
-                rows = _rows_per_read(offsets, smems)
-                counts, out = o.find_smems_batch(algo, reads, nthreads=8)
-                st = st.cpu().numpy()
-                for r in range(N):
-                    if counts[r] < 0:
-                        assert st[r] != 0, (n, K, L, algo, r)
-                    else:
-                        assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (n, K, L, algo, r)
-                cases += 1
-    assert cases == 54
+            want = {}
+            for fmt in ("wide", "compact"):                                 # both forms of the match table
+                ix = pkg.GenieIndex.build(ref, K, table_format=fmt)
+                coefs, icpts, _, _, _ = ix.train_rmi([10])
+                ix = ix.to("cuda")
+                o.set_rmi([10], coefs, icpts)
+                for algo in ("bwa", "lut", "rmi"):
+                    offsets, smems, st = ix.find_smems(algo, reads)
+                    rows = _rows_per_read(offsets, smems)
+                    if algo not in want:
+                        want[algo] = o.find_smems_batch(algo, reads, nthreads=8)
+                    counts, out = want[algo]
+                    st = st.cpu().numpy()
+                    for r in range(N):
+                        if counts[r] < 0:
+                            assert st[r] != 0, (n, K, L, algo, fmt, r)
+                        else:
+                            assert st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist(), (n, K, L, algo, fmt, r)
+                    cases += 1
+    assert cases == 108
 
 
 def test_sampled_search_fuzz_lengths(pkg):
@@ -646,7 +650,7 @@ def test_absent_base_is_flagged(pkg):
 def test_report_helpers(pkg):
     """genie_search_kernel_name / genie_launch_info: what bench.py and the profile summaries key on."""
     ix = _index(pkg, "syn10k_K8")
-    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8>"     # the <4> build is for tables beyond an XCD's L2
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, false>"     # 32-byte entries: the table fits an XCD's L2
     assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel"
     info = ix.launch_info("lut", 150)
     assert info["block"] == 512 and 0 < info["lds_bytes"] <= 160 * 1024 and info["grid"] > 0
@@ -768,7 +772,7 @@ def test_one_megabase_reference(pkg, oracle_mod):
     r = pkg.RMI_LUT([1000], 15, "REF_1M.fa", matcher=m)
     r.train_RMI()
     ix = r._index()
-    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<4>"     # 8 MB table: the two-blocks-per-CU build
+    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<8, true>"      # 1 Mb: the compact table (4 MB of 16-byte entries)
     o = oracle_mod.Oracle(ref, 15)
     coefs, icpts = r.rmi.coefficients()
     o.set_rmi([1000], coefs, icpts)
@@ -961,3 +965,59 @@ def test_config4_eighty_million_reads_in_eight_shards(pkg, oracle_mod):
         del rd, off, rows, st
         torch.cuda.empty_cache()
     assert total_reads == 80_000_000 and 8 * total_reads < total_rows < 16 * total_reads
+
+
+# ------------------------------------------------------------------ the compact match table on the small fixtures
+@pytest.mark.parametrize("ds", [d for d in G.DATASETS if G.have(d)])
+def test_compact_table_golden_and_oracle(pkg, oracle_mod, ds):
+    """The compact (16-byte entry, 8-base key) match table is what references of more than ~260 kb get; here it is
+    forced on the golden datasets: every golden group's ordered rows against the reference's own outputs, and fresh
+    reads (from-ref, random, long exact copies of the reference, low complexity, ragged lengths, 256 .. 3000 bases)
+    against the CPU oracle, with the sampled and the every-position lookup."""
+    import torch
+    d, _ = G.load(ds)
+    ref, K = d["ref_codes"], int(d["K"])
+    ix = pkg.GenieIndex.build(ref, K, table_format="compact")
+    coefs, icpts, _, _, _ = ix.train_rmi([10, 100] if ds.startswith("medium") else [1000])
+    ix = ix.to("cuda")
+    assert "true>" in ix.search_kernel_name("lut", 150)
+    for dsg, tag, algo in G.group_cases():
+        if dsg != ds or algo == "rmi":
+            continue
+        rd = G.reads(ds, tag)
+        items = G.ref_items(ds, tag, algo)
+        offsets, smems, st = ix.find_smems(algo, rd[:len(items)], min_len=1)
+        assert (st.cpu().numpy() == 0).all()
+        rows = _rows_per_read(offsets, smems)
+        for r in range(len(items)):
+            assert G.dict_view(rd[r], rows[r]) == items[r], (tag, algo, r)
+    o = oracle_mod.Oracle(ref, K)
+    o.set_rmi([10, 100] if ds.startswith("medium") else [1000], coefs, icpts)
+    from genie_smem_amd import synth as B
+    rng = np.random.default_rng(31)
+    n = len(ref)
+    batches = [B.reads_from_ref(ref, 700, 150, 41), B.reads_random(300, 150, 42), B.reads_from_ref(ref, 60, 1500, 43)]
+    exact = np.stack([ref[p:p + 250] for p in rng.integers(0, n - 250, 200)])            # long exact matches
+    exact[::2, 125] = (exact[::2, 125] + 1) % 4                                          # ... half of them with one substitution
+    batches.append(exact)
+    low = np.tile(rng.integers(0, 4, (100, 5)).astype(np.uint8), (1, 30))               # period-5 reads
+    batches.append(low)
+    batches.append(np.concatenate([ref[n - 300:], ref[:300]])[None, :].repeat(3, 0).astype(np.uint8))   # the reference's end, then its start
+    for rd in batches:
+        for sa in (0, 1):
+            ix.set_option(pkg._native.OPT_SEARCH_ALL, sa)
+            for algo in ("bwa", "lut", "rmi"):
+                offsets, smems, st = ix.find_smems(algo, rd)
+                assert int(st.abs().sum().item()) == 0
+                rows = _rows_per_read(offsets, smems)
+                counts, want = o.find_smems_batch(algo, rd, nthreads=16)
+                for i in range(len(rd)):
+                    assert rows[i].tolist() == want[i, :counts[i]].tolist(), (algo, sa, rd.shape, i)
+    ix.set_option(pkg._native.OPT_SEARCH_ALL, 0)
+    lens = rng.integers(K, 151, 500).astype(np.int32)                                    # ragged
+    rd = B.reads_from_ref(ref, 500, 150, 44)
+    offsets, smems, st = ix.find_smems("lut", torch.as_tensor(rd).cuda(), lens=torch.as_tensor(lens).cuda())
+    rows = _rows_per_read(offsets, smems)
+    counts, want = o.find_smems_batch("lut", rd, nthreads=16, lens=lens)
+    for i in range(500):
+        assert rows[i].tolist() == want[i, :counts[i]].tolist(), i

@@ -117,7 +117,7 @@ def test_reference_checked_in_fixtures(pkg):
 
 
 # ------------------------------------------------------------------ image + prefix directory
-HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqiiqqqq")
+HDR = struct.Struct("<QIIqqiiqqqqqqqqqqi4i4i5i8Iqqiiqqqqqq")
 
 
 def _parse(img):
@@ -125,11 +125,12 @@ def _parse(img):
     keys = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
             "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
     h = dict(zip(keys, f[:18]))
-    h["padtail"] = list(f[-16:-8])
-    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-8], f[-7], f[-6]
-    h["flags"] = f[-5]
-    h["off_rmi_err"], h["rmi_err_entries"] = f[-4], f[-3]
-    h["off_mtab"], h["mtab_entries"] = f[-2], f[-1]
+    h["padtail"] = list(f[-18:-10])
+    h["off_dir2"], h["dir2_entries"], h["P2"] = f[-10], f[-9], f[-8]
+    h["flags"] = f[-7]
+    h["off_rmi_err"], h["rmi_err_entries"] = f[-6], f[-5]
+    h["off_mtab"], h["mtab_entries"] = f[-4], f[-3]
+    h["off_ov"], h["ov_entries"] = f[-2], f[-1]
     return h
 
 
@@ -360,11 +361,11 @@ def test_match_table_against_brute_force(pkg, case):
         ref = np.concatenate([np.tile([0, 1, 2, 3, 3, 1], 60), rng.integers(0, 4, 1000), np.tile([2, 2, 0, 1, 3, 0, 1, 1, 2, 3], 11),
                               rng.integers(0, 4, 1000)]).astype(np.uint8)
     n = len(ref)
-    ix = pkg.GenieIndex.build(ref, 6)
+    ix = pkg.GenieIndex.build(ref, 6, table_format="wide")
     img = ix.serialize().numpy()
     h = _parse(img)
     P2 = h["P2"]
-    assert h["dir2_entries"] == 4 ** P2 <= h["mtab_entries"]
+    assert h["dir2_entries"] == 4 ** P2 <= h["mtab_entries"] and h["flags"] & 2 == 0 and h["ov_entries"] == 0
     mt = _match_table(img, h)
     raw = np.frombuffer(bytes(img[h["off_mtab"]:h["off_mtab"] + 32 * h["mtab_entries"]]), "<u4").reshape(-1, 8)
     base, lmask = mt["meta"] & 0xFF, (mt["meta"] >> 8) & 0xFF
@@ -421,6 +422,83 @@ def test_match_table_against_brute_force(pkg, case):
             assert (int(mt["lb"][c]), int(mt["key"][c][0])) == (want[0], want[-1]) and len(want) == want[-1] - want[0] + 1, mer
 
 
+@pytest.mark.parametrize("case", ["syn10k", "tail_A", "tiny", "repeat"])
+def test_compact_match_table_against_brute_force(pkg, case):
+    """MatchRec16 per P2-mer + its overflow blocks (genie_internal.h, the form for tables that do not fit an XCD's L2):
+    first row, suffix count, the 8-base continuations (inline up to six; 7 .. 13: five inline + a block of eight), the
+    rows-decide flag (a cut-short suffix, or more than 13) and, for an absent P2-mer, its longest occurring prefix and that
+    prefix's rows -- against a direct enumeration."""
+    rng = np.random.default_rng(77)
+    if case == "syn10k":
+        ref = rng.integers(0, 4, 10_000).astype(np.uint8)
+    elif case == "tail_A":
+        ref = np.concatenate([rng.integers(0, 4, 3000), np.zeros(40, np.int64)]).astype(np.uint8)
+    elif case == "tiny":
+        ref = rng.integers(0, 4, 13).astype(np.uint8)
+    else:
+        ref = np.concatenate([np.tile([0, 1, 2, 3, 3, 1], 60), rng.integers(0, 4, 1000), np.tile([2, 2, 0, 1, 3, 0, 1, 1, 2, 3], 11),
+                              rng.integers(0, 4, 1000)]).astype(np.uint8)
+    n = len(ref)
+    ix = pkg.GenieIndex.build(ref, 6, table_format="compact")
+    img = ix.serialize().numpy()
+    h = _parse(img)
+    P2 = h["P2"]
+    assert h["flags"] & 2 and h["mtab_entries"] == h["dir2_entries"] == 4 ** P2 and 1 <= h["ov_entries"] <= 65536
+    raw = np.frombuffer(bytes(img[h["off_mtab"]:h["off_mtab"] + 16 * h["mtab_entries"]]), np.dtype([("w0", "<u4"), ("key", "<u2", (6,))]))
+    ov = np.frombuffer(bytes(img[h["off_ov"]:h["off_ov"] + 16 * h["ov_entries"]]), "<u2").reshape(-1, 8)
+    lb, cnt4, nib = raw["w0"] & 0xFFFFFF, (raw["w0"] >> 24) & 15, raw["w0"] >> 28
+    s = "".join("ACGT"[c] for c in ref)
+    occ = [set()] + [{s[i:i + t] for i in range(n - t + 1)} for t in range(1, P2 + 1)]
+    sa0 = ix.suffix_array().astype(np.int64) - 1
+
+    def key_of(st):
+        k = 0
+        for j in range(8):
+            k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (14 - 2 * j)
+        return k
+
+    by_code, first_row = {}, {}
+    for row, st in enumerate(sa0):
+        if n - st >= P2:
+            by_code.setdefault(s[st:st + P2], []).append(int(st))
+            first_row.setdefault(s[st:st + P2], row)
+    code_of = lambda t: int("".join(str("ACGT".index(c)) for c in t), 4)        # noqa: E731
+    blocks, many = set(), 0
+    for mer, starts in by_code.items():
+        c = code_of(mer)
+        keys = [key_of(st) for st in starts]
+        k = len(starts)
+        cut = any(n - st < P2 + 8 for st in starts)
+        assert lb[c] == first_row[mer]
+        assert cut or keys == sorted(keys)
+        if 7 <= k <= 13 and not cut:
+            assert cnt4[c] == 7 and nib[c] == k - 7 and raw["key"][c][:5].tolist() == keys[:5], mer
+            b = int(raw["key"][c][5])
+            assert 1 <= b < h["ov_entries"] and b not in blocks
+            blocks.add(b)
+            assert ov[b].tolist() == keys[5:] + [keys[5]] * (13 - k), mer
+        else:
+            many += k > 13
+            assert cnt4[c] == min(k, 6) and nib[c] == (8 if cut or k > 6 else 0), mer
+            assert raw["key"][c].tolist() == ((keys + [keys[0]] * 6)[:6] if k <= 6 else keys[:6]), mer
+    assert len(blocks) == h["ov_entries"] - 1
+    if case == "repeat":
+        assert len(blocks) >= 5 and many >= 1
+    absent = np.nonzero(cnt4 == 0)[0]
+    assert len(absent) == 4 ** P2 - len(by_code)
+    for c in (absent if len(absent) < 3000 else rng.choice(absent, 3000, replace=False)):
+        mer = "".join("ACGT"[(int(c) >> (2 * (P2 - 1 - j))) & 3] for j in range(P2))
+        t = max([t for t in range(1, P2) if mer[:t] in occ[t]], default=0)
+        assert nib[c] == t, mer
+        if t:
+            want = [row for row, st in enumerate(sa0) if s[st:st + t] == mer[:t]]
+            last = int(raw["key"][c][0]) | int(raw["key"][c][1]) << 16
+            assert (int(lb[c]), last) == (want[0], want[-1]) and len(want) == want[-1] - want[0] + 1, mer
+    # the form is chosen by the size of the 32-byte table (4 MB = an XCD's L2) unless the caller asks
+    small = _parse(pkg.GenieIndex.build(ref, 6).serialize().numpy())
+    assert small["flags"] & 2 == 0 and small["ov_entries"] == 0
+
+
 def test_corrupt_image_is_rejected(pkg):
     """genie_index_open validates every section of the image header: a truncated or corrupt image must
     come back as GENIE_E_BAD_BLOB, not as device pointers outside the allocation.  (Host-side check:
@@ -448,8 +526,8 @@ def test_corrupt_image_is_rejected(pkg):
     names = ["magic", "version", "header_bytes", "total_bytes", "n", "K", "P", "off_sa", "off_ref", "off_dir",
              "off_lut", "off_rmi", "ref_recs", "dir_entries", "lut_slots", "lut_keys", "rmi_models", "nlev"]
     pos = {k: i for i, k in enumerate(names)}
-    tail = {"off_dir2": -8, "dir2_entries": -7, "P2": -6, "off_rmi_err": -4, "rmi_err_entries": -3, "off_mtab": -2,
-            "mtab_entries": -1}
+    tail = {"off_dir2": -10, "dir2_entries": -9, "P2": -8, "flags": -7, "off_rmi_err": -6, "rmi_err_entries": -5, "off_mtab": -4,
+            "mtab_entries": -3, "off_ov": -2, "ov_entries": -1}
 
     def corrupt(**kw):
         f = list(fields)

@@ -7,7 +7,7 @@ from genie_smem_amd import synth
 n = int(os.environ.get("REF_N", 100_000)); N = int(os.environ.get("READS", 1_000_000)); L = int(os.environ.get("READ_LEN", 150))
 mode = os.environ.get("MODE", "lut")
 ref = synth.synth_ref(n, n)
-ix = g.GenieIndex.build(ref, 15, table_bits=int(os.environ.get("TABLE_BITS", "0")))
+ix = g.GenieIndex.build(ref, 15, table_bits=int(os.environ.get("TABLE_BITS", "0")), table_format=os.environ.get("FMT", "auto"))
 ix.train_rmi([1000])
 ix = ix.to("cuda")
 kind = os.environ.get("KIND", "fromref")
