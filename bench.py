@@ -115,32 +115,59 @@ def cpu_baseline(ref, cfg, rl, mode, sample_reads):
                       f"OpenMP over reads, {dt:.2f} s wall"}, rd, counts, rows
 
 
-def from_host_rate(lib, ix, mode_id, host_reads, L, rows_per_read, steps=6):
-    """Section 8(d)'s metric as SURVEY words it: pinned host reads -> H2D -> the call -> D2H of offsets and rows,
-    double-buffered on two streams.  The host link sets this rate; it is never `value`."""
+def from_host_rate(lib, ix, mode_id, host_reads, L, rows_per_read, steps=6, packed=True):
+    """Section 8(d)'s metric as SURVEY words it: pinned host reads -> H2D -> the call -> D2H of the results,
+    double-buffered on two streams.  The host link sets this rate; it is never `value`.
+    packed: genie_find_smems_packed -- 2-bit packed reads in (40 B per 150-base read), a count and a status byte per read
+    and 8-byte rows out; else genie_find_smems_csr -- one byte per base in, int64 offsets and 16-byte rows out."""
+    from genie_smem_amd import packing
     N = host_reads.shape[0]
     cap = int(N * rows_per_read * 1.05) + 1024
     P = lambda t: C.c_void_p(t.data_ptr())                                       # noqa: E731
+    if packed:
+        host_in = torch.as_tensor(packing.pack_reads(host_reads.numpy())).pin_memory()      # host-side layout, outside the timing
+    else:
+        host_in = host_reads
 
     class Buf:
         def __init__(self):
             self.stream = torch.cuda.Stream()
-            self.reads = torch.empty((N, L), dtype=torch.uint8, device="cuda")
-            self.status = torch.empty(N, dtype=torch.int32, device="cuda")
-            self.offsets = torch.empty(N + 1, dtype=torch.int64, device="cuda")
-            self.rows = torch.empty((cap, 4), dtype=torch.int32, device="cuda")
+            self.reads = torch.empty(tuple(host_in.shape), dtype=torch.uint8, device="cuda")
             self.ws_b = int(lib.genie_find_smems_workspace_bytes(N, L))
             self.ws = torch.empty(self.ws_b, dtype=torch.uint8, device="cuda")
-            self.h_off = torch.empty(N + 1, dtype=torch.int64).pin_memory()
-            self.h_rows = torch.empty((cap, 4), dtype=torch.int32).pin_memory()
+            if packed:
+                self.counts8 = torch.empty(N, dtype=torch.uint8, device="cuda")
+                self.status8 = torch.empty(N, dtype=torch.uint8, device="cuda")
+                self.rows = torch.empty((cap, 8), dtype=torch.uint8, device="cuda")
+                self.totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+                self.esc = torch.empty((1024, 2), dtype=torch.int64, device="cuda")
+                self.h_counts = torch.empty(N, dtype=torch.uint8).pin_memory()
+                self.h_status = torch.empty(N, dtype=torch.uint8).pin_memory()
+                self.h_rows = torch.empty((cap, 8), dtype=torch.uint8).pin_memory()
+                self.h_totals = torch.empty(2, dtype=torch.int64).pin_memory()
+            else:
+                self.status = torch.empty(N, dtype=torch.int32, device="cuda")
+                self.offsets = torch.empty(N + 1, dtype=torch.int64, device="cuda")
+                self.rows = torch.empty((cap, 4), dtype=torch.int32, device="cuda")
+                self.h_off = torch.empty(N + 1, dtype=torch.int64).pin_memory()
+                self.h_rows = torch.empty((cap, 4), dtype=torch.int32).pin_memory()
 
         def run(self):
             with torch.cuda.stream(self.stream):
-                self.reads.copy_(host_reads, non_blocking=True)
-                g._native.check(lib.genie_find_smems_csr(ix._h, mode_id, P(self.reads), None, N, L, L, 1, P(self.offsets),
-                                                         P(self.rows), cap, P(self.status), P(self.ws), self.ws_b,
-                                                         C.c_void_p(self.stream.cuda_stream)), "genie_find_smems_csr")
-                self.h_off.copy_(self.offsets, non_blocking=True)
+                self.reads.copy_(host_in, non_blocking=True)
+                sp = C.c_void_p(self.stream.cuda_stream)
+                if packed:
+                    g._native.check(lib.genie_find_smems_packed(ix._h, mode_id, P(self.reads), None, N, host_in.shape[1], L, 1,
+                                                                P(self.counts8), P(self.status8), P(self.rows), cap, P(self.totals),
+                                                                P(self.esc), 1024, P(self.ws), self.ws_b, sp), "genie_find_smems_packed")
+                    self.h_counts.copy_(self.counts8, non_blocking=True)
+                    self.h_status.copy_(self.status8, non_blocking=True)
+                    self.h_totals.copy_(self.totals, non_blocking=True)
+                else:
+                    g._native.check(lib.genie_find_smems_csr(ix._h, mode_id, P(self.reads), None, N, L, L, 1, P(self.offsets),
+                                                             P(self.rows), cap, P(self.status), P(self.ws), self.ws_b, sp),
+                                    "genie_find_smems_csr")
+                    self.h_off.copy_(self.offsets, non_blocking=True)
                 self.h_rows.copy_(self.rows, non_blocking=True)
 
     bufs = [Buf(), Buf()]
@@ -152,8 +179,14 @@ def from_host_rate(lib, ix, mode_id, host_reads, L, rows_per_read, steps=6):
         bufs[i & 1].run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / steps
-    assert int(bufs[0].h_off[-1]) <= cap
-    return N * L / dt, dt * 1e3
+    if packed:
+        assert int(bufs[0].h_totals[0]) <= cap and int(bufs[0].h_totals[1]) == 0 and int(bufs[0].h_status.sum()) == 0
+        assert int(bufs[0].h_counts.to(torch.int64).sum()) == int(bufs[0].h_totals[0])
+        bytes_per_read = host_in.shape[1] + 2 + 8.0 * cap / N
+    else:
+        assert int(bufs[0].h_off[-1]) <= cap
+        bytes_per_read = L + 8 + 16.0 * cap / N
+    return N * L / dt, dt * 1e3, bytes_per_read
 
 
 def load_counters(key):
@@ -422,11 +455,17 @@ def main():
             "roofline": roof,
         }
         lib = g._native.lib()
-        if world == 1 and not args.no_from_host and n_reads <= 2_000_000:
-            v, ms = from_host_rate(lib, ix, g._native.MODES[mode], w["reads"].cpu().pin_memory(), L, S)
-            line["value_from_host"] = {"value": v, "unit": "query-bases/s", "ms_per_step": ms,
-                                       "what": "pinned host reads -> H2D -> call -> D2H of offsets + rows, double-buffered on two "
-                                               "streams (SURVEY 8d's wording of the metric; host-link bound; never `value`)"}
+        if world == 1 and not args.no_from_host and n_reads <= 2_000_000 and L <= 255:
+            host_reads = w["reads"].cpu().pin_memory()
+            v, ms, bpr = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=True)
+            v0, ms0, bpr0 = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=False)
+            line["value_from_host"] = {"value": v, "unit": "query-bases/s", "ms_per_step": ms, "link_bytes_per_read": round(bpr, 1),
+                                       "what": "pinned host reads, 2-bit packed -> H2D -> genie_find_smems_packed -> D2H of count / status "
+                                               "bytes + 8-byte rows, double-buffered on two streams (SURVEY 8d's wording of the metric; "
+                                               "host-link bound; never `value`)",
+                                       "unpacked": {"value": v0, "ms_per_step": ms0, "link_bytes_per_read": round(bpr0, 1),
+                                                    "what": "the same through genie_find_smems_csr: a byte per base in, int64 offsets + 16-byte rows out"}}
+            del host_reads
         if not args.no_cpu_baseline and world == 1:
             base, rd_s, cnt_s, rows_s = cpu_baseline(w["ref_codes"], cfg, w["rl"], mode, args.cpu_sample)
             line["cpu_baseline"] = base

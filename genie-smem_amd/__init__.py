@@ -12,7 +12,7 @@ from .lut import LUT
 from .rmi import RMI
 from .rmi_lut import RMI_LUT
 from .smem import SMEM, create_query_from_ref, create_random_query
-from . import parallel
+from . import packing, parallel
 
-__all__ = ["ExactMatch", "LUT", "RMI", "RMI_LUT", "SMEM", "GenieIndex", "parallel", "_native",
+__all__ = ["ExactMatch", "LUT", "RMI", "RMI_LUT", "SMEM", "GenieIndex", "parallel", "packing", "_native",
            "create_query_from_ref", "create_random_query"]

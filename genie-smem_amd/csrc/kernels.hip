@@ -752,6 +752,12 @@ struct CsrOut {
     int64_t *offsets = nullptr;      // non-null => write CSR rows to `rows`, else slots
     int32_t *rows = nullptr;
     int64_t cap_rows = 0;
+    // genie_find_smems_packed: 2-bit packed reads in; 8-byte rows, a count byte and a status byte per read out.
+    // `offsets` then points at the totals (word 0 = rows, word 1 = escapes); `rows` at the 8-byte rows.
+    bool packed = false;
+    uint8_t *counts8 = nullptr, *status8 = nullptr;
+    int64_t *escapes = nullptr;
+    int64_t cap_escapes = 0;
 };
 
 template <int MODE, bool WIDE>
@@ -771,8 +777,10 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
-        auto km = c16 ? (g.wps == 4 ? match_table_kernel<4, true> : match_table_kernel<8, true>)
-                      : (g.wps == 4 ? match_table_kernel<4, false> : match_table_kernel<8, false>);
+        auto km = csr.packed ? (c16 ? (g.wps == 4 ? match_table_kernel<4, true, true> : match_table_kernel<8, true, true>)
+                                    : (g.wps == 4 ? match_table_kernel<4, false, true> : match_table_kernel<8, false, true>))
+                             : (c16 ? (g.wps == 4 ? match_table_kernel<4, true, false> : match_table_kernel<8, true, false>)
+                                    : (g.wps == 4 ? match_table_kernel<4, false, false> : match_table_kernel<8, false, false>));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, st,
@@ -800,7 +808,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
         hipLaunchKernelGGL(kb, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), lds_b, s, ix->dev, d_lens, (long long)N,
                            fixed_len, min_len, ws.fwd, g.fwd_stride, g.fwd_lds, cnt, ws.kj, g.kj_row, head, head_stride,
-                           csr.offsets ? g.kj_row : cap, st, bsums);
+                           csr.offsets ? g.kj_row : cap, st, bsums, csr.counts8, csr.status8);
     }
     HIP_TRY(hipGetLastError());
     int block_shift = 0;
@@ -817,15 +825,28 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     long long grid_c = (long long)cus * (32 / kIvWaves);
     const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
+    RowEscapes esc{nullptr, nullptr, 0};
+    if (csr.packed) {
+        esc.count = reinterpret_cast<unsigned long long *>(csr.offsets) + 1;
+        esc.list = reinterpret_cast<long long *>(csr.escapes);
+        esc.cap = csr.cap_escapes;
+        HIP_TRY(hipMemsetAsync(csr.offsets, 0, 16, s));
+        auto kp = c16 ? interval_kernel<true, false, true, true> : interval_kernel<true, false, false, true>;
+        hipLaunchKernelGGL(kp, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(csr.rows), 0,
+                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc);
+        HIP_TRY(hipGetLastError());
+        return GENIE_OK;
+    }
     auto kc = csr.offsets ? (c16 ? interval_kernel<true, WIDE, true> : interval_kernel<true, WIDE, false>)
                           : (c16 ? interval_kernel<false, WIDE, true> : interval_kernel<false, WIDE, false>);
     if (csr.offsets)
         hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
-                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(csr.rows), 0,
-                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift);
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(csr.rows), 0,
+                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc);
     else
         hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
-                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<int4 *>(d_slots), cap, nullptr, 0ll, nullptr, nullptr, 0);
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(d_slots), cap, nullptr, 0ll, nullptr, nullptr, 0, esc);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }
@@ -873,10 +894,11 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
 int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap)
 {
     (void)mode;
+    // match_table_kernel<waves per SIMD, compact table, packed reads> (the unpacked-reads instance: what bench.py times)
     const bool big = table_bytes(ix) > kTableFitsL2, c16 = (ix->dev.flags & kFlagCompactTable) != 0;
     const char *name = max_len > 255 ? (c16 ? "match_table_long_kernel<true>" : "match_table_long_kernel<false>")
-                                     : (big ? (c16 ? "match_table_kernel<4, true>" : "match_table_kernel<4, false>")
-                                            : (c16 ? "match_table_kernel<8, true>" : "match_table_kernel<8, false>"));
+                                     : (big ? (c16 ? "match_table_kernel<4, true, false>" : "match_table_kernel<4, false, false>")
+                                            : (c16 ? "match_table_kernel<8, true, false>" : "match_table_kernel<8, false, false>"));
     if (!buf || cap < (int)strlen(name) + 1) return GENIE_E_CAPACITY;
     memcpy(buf, name, strlen(name) + 1);
     return GENIE_OK;
@@ -939,6 +961,28 @@ int launch_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_
     csr.rows = d_rows;
     csr.cap_rows = out_cap_rows;
     return launch_find_any(ix, mode, d_reads, d_lens, N, stride, fixed_len, min_len, nullptr, nullptr, 0, d_status, d_ws,
+                           ws_bytes, csr, stream);
+}
+
+int launch_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *d_reads2, const int32_t *d_lens, int64_t N,
+                             int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
+                             void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
+                             void *d_ws, int64_t ws_bytes, void *stream)
+{
+    if (N == 0) {
+        HIP_TRY(hipMemsetAsync(d_totals, 0, 16, (hipStream_t)stream));
+        return GENIE_OK;
+    }
+    CsrOut csr;
+    csr.offsets = d_totals;
+    csr.rows = reinterpret_cast<int32_t *>(d_rows8);
+    csr.cap_rows = out_cap_rows;
+    csr.packed = true;
+    csr.counts8 = d_counts8;
+    csr.status8 = d_status8;
+    csr.escapes = d_escapes;
+    csr.cap_escapes = cap_escapes;
+    return launch_find_any(ix, mode, d_reads2, d_lens, N, stride_bytes, fixed_len, min_len, nullptr, nullptr, 0, nullptr, d_ws,
                            ws_bytes, csr, stream);
 }
 

@@ -34,6 +34,19 @@ class SMEM:
         self.rmi_lut = None
 
     # ------------------------------------------------------------------ batched entry points
+    def _reads_codes(self, reads):
+        """list[str] | ndarray -> (uint8 [N, width] numpy codes, int32 lens or None)."""
+        if isinstance(reads, np.ndarray):
+            return np.ascontiguousarray(reads, np.uint8), None
+        enc = [self.matcher.encode(r) for r in reads]
+        lens = np.asarray([len(e) for e in enc], np.int32)
+        width = int(lens.max()) if len(enc) else 1
+        mat = np.zeros((len(enc), max(width, 1)), np.uint8)
+        for i, e in enumerate(enc):
+            mat[i, :len(e)] = e
+        ragged = len(enc) > 0 and int(lens.min()) != width
+        return mat, (lens if ragged else None)
+
     def _reads_tensor(self, reads):
         """list[str] | ndarray | tensor -> (uint8 [N, stride] on the device, lens or None)."""
         ix_dev = torch.device(self.matcher.device)
@@ -58,6 +71,13 @@ class SMEM:
             ix = self.rmi_lut._index()
         else:
             ix = self.matcher.index(K)
+        if not isinstance(reads, torch.Tensor):
+            # host inputs: 2-bit packed over the host link, 8-byte rows back (genie_find_smems_packed); results on the host
+            codes, l2 = self._reads_codes(reads)
+            if codes.shape[1] <= 255:
+                ln = lens if lens is not None else l2
+                off, rows, st = ix.find_smems_host(mode, codes, ln, min_len)
+                return torch.as_tensor(off), torch.as_tensor(rows), torch.as_tensor(st)
         t, l2 = self._reads_tensor(reads)
         return ix.find_smems(mode, t, lens if lens is not None else l2, min_len)
 

@@ -208,6 +208,24 @@ int genie_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_r
                          int32_t *d_rows, int64_t out_cap_rows, int32_t *d_status, void *d_workspace,
                          int64_t workspace_bytes, void *stream);
 
+/* The same discovery for callers on the far side of a host link (SMEM.find_smems_* on host arrays): 2-bit packed reads in,
+ * 8-byte rows out -- 40 instead of 150 bytes per 150-base read over PCIe, 8 instead of 16 per SMEM.  Reads of at most 255
+ * bases.  Row r of d_reads2bit = stride_bytes bytes (a multiple of 4, >= 4 * ceil(max length / 16)): byte i holds bases
+ * 4i .. 4i+3, base 4i in bits 7..6 (codes as above; bases past the read's length are ignored).  Output:
+ *   d_counts8[r]  SMEMs of read r (flagged reads: 0);  d_status8[r] = its GENIE_READ_* code;
+ *   d_rows8       dense, reads in input order, SMEMs in emission order (the CSR rows of genie_find_smems_csr; a read's
+ *                 rows start at the sum of the counts before it), 8 bytes each: byte 0 start, byte 1 end, bytes 2..3
+ *                 span = hi - lo (little endian), bytes 4..7 lo.  span == 0xFFFF means "65535 or more": that row's
+ *                 index and its hi are also appended to d_escapes (int64 pairs: row, hi; unordered);
+ *   d_totals[0]   rows in all (rows beyond out_cap_rows were dropped);  d_totals[1] = escapes in all (compare with
+ *                 cap_escapes and call again with a larger list if it is exceeded).
+ * The reference has no counterpart (its API is in-process Python strings); genie-smem_amd/packing.py holds the host side:
+ * pack_reads() and unpack_rows() give back exactly the int32 (start, end, lo, hi) rows of genie_find_smems_csr. */
+int genie_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *d_reads2bit, const int32_t *d_lens, int64_t N,
+                            int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
+                            void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
+                            void *d_workspace, int64_t workspace_bytes, void *stream);
+
 /* Compact the slotted output to CSR: d_offsets[N+1] (exclusive prefix sum of min(count,cap))
  * and d_out[total*4].  d_tmp: scratch of genie_compact_tmp_bytes(N) bytes. */
 int64_t genie_compact_tmp_bytes(int64_t N);

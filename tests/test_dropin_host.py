@@ -171,3 +171,27 @@ def test_workspace_rows_and_index_create_ex_arguments():
     assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 0, 5, C.byref(h)) == -1       # (dir_bits 0 = 7)
     assert lib.genie_index_create_ex(codes.ctypes.data_as(u8p), 64, None, 6, 7, 9, C.byref(h)) == 0
     lib.genie_index_destroy(h)
+
+
+def test_packing_layouts():
+    """packing.pack_reads / unpack_rows: the host side of genie_find_smems_packed (layout conversions only)."""
+    from genie_smem_amd import packing
+    rng = np.random.default_rng(1)
+    for L in (1, 3, 4, 15, 16, 17, 100, 150, 255):
+        c = rng.integers(0, 4, (9, L)).astype(np.uint8)
+        p = packing.pack_reads(c)
+        assert p.shape == (9, packing.packed_stride(L)) and p.shape[1] % 4 == 0 and p.shape[1] >= 4 * ((L + 15) // 16)
+        assert (packing.unpack_reads(p, L) == c).all()
+        assert p[0, 0] >> 6 == c[0, 0]                                   # the first base in the top bits of byte 0
+        assert (p[:, (L + 3) // 4:] == 0).all()
+    with pytest.raises(KeyError):
+        packing.pack_reads(np.array([[0, 4, 1]], np.uint8))
+    counts = np.array([2, 0, 1], np.uint8)
+    r8 = np.zeros(3, packing.ROW8)
+    r8["start"], r8["end"], r8["span"], r8["lo"] = [0, 5, 0], [5, 9, 4], [0, 0xFFFF, 3], [7, 100, 9]
+    off, rows = packing.unpack_rows(counts, r8.view(np.uint8), np.array([[1, 70100], [9, 1]]))       # (an escape of a dropped row is ignored)
+    assert off.tolist() == [0, 2, 2, 3] and rows.tolist() == [[0, 5, 7, 7], [5, 9, 100, 70100], [0, 4, 9, 12]]
+    with pytest.raises(ValueError):
+        packing.unpack_rows(counts, r8.view(np.uint8), np.zeros((0, 2), np.int64))
+    with pytest.raises(ValueError):
+        packing.unpack_rows(counts, r8.view(np.uint8))

@@ -650,8 +650,8 @@ def test_absent_base_is_flagged(pkg):
 def test_report_helpers(pkg):
     """genie_search_kernel_name / genie_launch_info: what bench.py and the profile summaries key on."""
     ix = _index(pkg, "syn10k_K8")
-    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, false>"     # 32-byte entries: the table fits an XCD's L2
-    assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel"
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, false, false>"     # 32-byte entries: the table fits an XCD's L2
+    assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel<false>"
     info = ix.launch_info("lut", 150)
     assert info["block"] == 512 and 0 < info["lds_bytes"] <= 160 * 1024 and info["grid"] > 0
     # the stage switches are ignored unless the search kernel runs alone
@@ -772,7 +772,7 @@ def test_one_megabase_reference(pkg, oracle_mod):
     r = pkg.RMI_LUT([1000], 15, "REF_1M.fa", matcher=m)
     r.train_RMI()
     ix = r._index()
-    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<8, true>"      # 1 Mb: the compact table (4 MB of 16-byte entries)
+    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<8, true, false>"      # 1 Mb: the compact table (4 MB of 16-byte entries)
     o = oracle_mod.Oracle(ref, 15)
     coefs, icpts = r.rmi.coefficients()
     o.set_rmi([1000], coefs, icpts)
@@ -980,7 +980,7 @@ def test_compact_table_golden_and_oracle(pkg, oracle_mod, ds):
     ix = pkg.GenieIndex.build(ref, K, table_format="compact")
     coefs, icpts, _, _, _ = ix.train_rmi([10, 100] if ds.startswith("medium") else [1000])
     ix = ix.to("cuda")
-    assert "true>" in ix.search_kernel_name("lut", 150)
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, true, false>"
     for dsg, tag, algo in G.group_cases():
         if dsg != ds or algo == "rmi":
             continue
@@ -1021,3 +1021,70 @@ def test_compact_table_golden_and_oracle(pkg, oracle_mod, ds):
     counts, want = o.find_smems_batch("lut", rd, nthreads=16, lens=lens)
     for i in range(500):
         assert rows[i].tolist() == want[i, :counts[i]].tolist(), i
+
+
+# ------------------------------------------------------------------ packed reads in, 8-byte rows out
+def test_packed_entry_point_equals_csr(pkg, oracle_mod):
+    """genie_find_smems_packed (2-bit packed reads, count / status bytes, 8-byte rows + escape list) gives, after
+    packing.unpack_rows, exactly the offsets / int32 rows / status of genie_find_smems_csr: golden datasets with both table
+    forms, ragged lengths, a flagged read, every length 1 .. 40 and 239 .. 255, the 10^6-read batch; and row spans of
+    65535 or more (a reference in which every A is followed by C: the reads 'AG...' end an SMEM on a single base)."""
+    import torch
+    from genie_smem_amd import packing, synth as B
+    rng = np.random.default_rng(5)
+
+    def check(ix, mode, codes, lens=None, min_len=1):
+        want = ix.find_smems(mode, codes, lens=None if lens is None else torch.as_tensor(lens).cuda(), min_len=min_len)
+        c8, s8, r8, esc = ix.find_smems_packed(mode, torch.as_tensor(packing.pack_reads(codes)).cuda(), codes.shape[1],
+                                               lens=None if lens is None else torch.as_tensor(lens).cuda(), min_len=min_len)
+        off, rows = packing.unpack_rows(c8.cpu().numpy(), r8.cpu().numpy(), esc.cpu().numpy())
+        assert np.array_equal(off, want[0].cpu().numpy()) and np.array_equal(rows, want[1].cpu().numpy())
+        assert np.array_equal(s8.cpu().numpy().astype(np.int32), want[2].cpu().numpy())
+        return len(esc)
+
+    for ds in ("syn10k_K8", "big100k_K15"):
+        d, _ = G.load(ds)
+        ref, K = d["ref_codes"], int(d["K"])
+        for fmt in ("wide", "compact"):
+            ix = pkg.GenieIndex.build(ref, K, table_format=fmt)
+            ix.train_rmi([10])
+            ix = ix.to("cuda")
+            rd = np.concatenate([B.reads_from_ref(ref, 400, 150, 3), B.reads_random(200, 150, 4)])
+            for mode in ("bwa", "lut", "rmi"):
+                check(ix, mode, rd)
+            check(ix, "bwa", rd, min_len=12)
+            lens = rng.integers(K, 151, len(rd)).astype(np.int32)
+            check(ix, "lut", rd, lens)
+            for L in list(range(1, 41)) + list(range(239, 256)):
+                check(ix, "bwa", B.reads_from_ref(ref, 37, L, 100 + L))
+    # the full-size batch of BASELINE config 1 through the host-side entry: counts and every row
+    d, _ = G.load("syn100k_K15")
+    ix = _index_for(pkg, "syn100k_K15", "rmi")
+    rd = B.reads_from_ref_fast(d["ref_codes"], 1_000_000, 150, 1002)
+    assert check(ix, "lut", rd) == 0
+    off, rows, st = ix.find_smems_host("rmi", rd[:5000])
+    counts, want = oracle_mod.Oracle(d["ref_codes"], 15).find_smems_batch("lut", rd[:5000], nthreads=16)
+    assert (np.diff(off) == counts).all() and st.sum() == 0
+    for i in range(5000):
+        assert rows[off[i]:off[i + 1]].tolist() == want[i, :counts[i]].tolist(), i
+    # spans of 65535 rows or more go through the escape list
+    toks = [np.array(t, np.uint8) for t in ([0, 1], [1], [2], [3])]
+    ref = np.concatenate([toks[i] for i in rng.choice(4, 400_000, p=[0.3, 0.2, 0.25, 0.25])])
+    assert (ref == 0).sum() > 70_000 and not ((ref[:-1] == 0) & (ref[1:] != 1)).any()
+    ix = pkg.GenieIndex.build(ref, 2).to("cuda")
+    assert ix.search_kernel_name("bwa", 40) == "match_table_kernel<8, true, false>"
+    rd = rng.integers(0, 4, (300, 40)).astype(np.uint8)
+    rd[:, 0::7] = 0
+    rd[:, 1::7] = 2                                                   # 'AG': the A is an SMEM of one base
+    o = oracle_mod.Oracle(ref, 2)
+    assert check(ix, "bwa", rd) > 300
+    off, rows, st = ix.find_smems_host("bwa", rd)
+    counts, want = o.find_smems_batch("bwa", rd, nthreads=8)
+    assert (rows[:, 3] - rows[:, 2] >= 65535).sum() > 300
+    for i in range(300):
+        assert rows[off[i]:off[i + 1]].tolist() == want[i, :counts[i]].tolist(), i
+    # a bad base is caught while packing on the host, as the reference raises KeyError
+    bad = rd[:3].copy()
+    bad[1, 5] = 7
+    with pytest.raises(KeyError):
+        packing.pack_reads(bad)
