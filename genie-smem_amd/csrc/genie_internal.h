@@ -65,9 +65,9 @@ struct MatchRec {
 };
 static_assert(sizeof(MatchRec) == 32, "MatchRec must be one 32-byte fetch");
 
-// COMPACT match-table entry (16 bytes), the form used when the 32-byte form would not fit an XCD's L2 (references of
-// more than ~260 kb): on such tables the match-statistics kernel is bound by its L2 MISSES (each one a trip through the
-// fabric), so the table is halved: keys hold the 8 bases that follow the P2-mer instead of 16.
+// COMPACT match-table entry (16 bytes), the default form (references of fewer than 2^24 bases): on a table that does not
+// fit an XCD's L2 the match-statistics kernel is bound by its L2 MISSES (each one a trip through the fabric), so the
+// table is halved -- keys hold the 8 bases that follow the P2-mer instead of 16 -- and a lookup is ONE 16-byte load.
 //   w0 bits  0..23  lb     suffix-array row of the first suffix that starts with the P2-mer (n < 2^24)
 //      bits 24..27  cnt4   0: the P2-mer does not occur; 1..6: that many suffixes, their keys in key[0..cnt4) (unused
 //                          slots repeat key[0]); 7 (kM16More): 7 .. 13 suffixes -- key[0..4] hold the first five,
@@ -231,7 +231,7 @@ struct HostIndex {
     std::vector<int32_t> rmi_err;        // per leaf model (native training only)
 };
 
-// table_format: 0 = automatic (compact when the 32-byte table exceeds kTableFitsL2 and n < kM16MaxN), 1 = 32-byte entries,
+// table_format: 0 = automatic (compact when n < kM16MaxN), 1 = 32-byte entries,
 // 2 = compact entries
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
                      int32_t dir2_bits, int32_t table_format, HostIndex **out);

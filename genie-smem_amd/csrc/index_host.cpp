@@ -184,9 +184,10 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
             if (dir2_bits > P && dir2_bits <= 12) P2 = dir2_bits;       // build-time tuning (genie_index_create_ex)
             h->P2 = P2;
             const int64_t nb2 = (int64_t)1 << (2 * P2);
-            // table form: the 32-byte entries while they fit an XCD's L2, else the compact ones (genie_internal.h)
-            const bool compact = table_format == 2 ||
-                                 (table_format == 0 && nb2 * (int64_t)sizeof(MatchRec) > kTableFitsL2 && n < kM16MaxN);
+            // table form: the compact entries (genie_internal.h) wherever a row number fits their 24 bits -- they halve the
+            // L2 misses of a table that does not fit an XCD's L2, and measured 3.5 % faster on one that does (100 kb) --
+            // else the 32-byte ones
+            const bool compact = table_format == 2 || (table_format == 0 && n < kM16MaxN);
             const int KB = compact ? 8 : 16;                            // bases per key
             if (compact) h->flags |= kFlagCompactTable;
             h->dir2.assign((size_t)nb2, HeadRec{0, 0, 0});

@@ -42,8 +42,8 @@ class GenieIndex:
     def build(cls, codes, K, dir_bits=7, sa_one_based=None, table_bits=0, table_format="auto"):
         """codes: uint8 array of base codes 0..3; K: LUT / RMI key size (0 = none);
         sa_one_based: adopt this suffix array (reference JSON convention) instead of building;
-        table_bits: P2 of the per-P2-mer tables (0 = automatic); table_format: "auto" (compact entries once the 32-byte
-        table would exceed an XCD's L2), "wide" or "compact" -- tuning knobs of the index image only."""
+        table_bits: P2 of the per-P2-mer tables (0 = automatic); table_format: "auto" (compact 16-byte entries below 2^24
+        bases), "wide" or "compact" -- tuning knobs of the index image only."""
         codes = np.ascontiguousarray(codes, np.uint8)
         self = cls()
         u8p = C.POINTER(C.c_uint8)

@@ -104,8 +104,8 @@ int genie_index_create_from_sa(const uint8_t *codes, int64_t n, const int32_t *s
 /* genie_index_create / _from_sa (sa_one_based may be NULL) with the size of the per-P2-mer tables chosen by
  * the caller: table_bits = P2 in (dir_bits, 12] (anything else but 0 is GENIE_E_INVALID), 0 = automatic (smallest P2 with 4^P2 >= n/4: measured best on MI355X at n = 100 kb and 1 Mb).  A tuning
  * knob of the index image only: results do not depend on it.  The form of the per-P2-mer match table is chosen the same
- * way: GENIE_TABLE_WIDE / GENIE_TABLE_COMPACT ORed into table_bits, neither = automatic (compact once the 32-byte table
- * would exceed an XCD's 4 MB L2, i.e. references of more than ~260 kb). */
+ * way: GENIE_TABLE_WIDE / GENIE_TABLE_COMPACT ORed into table_bits, neither = automatic (compact: 16-byte entries, for
+ * every reference of fewer than 2^24 bases). */
 #define GENIE_TABLE_WIDE (1 << 8)    /* OR into table_bits: 32-byte entries with 16-base keys */
 #define GENIE_TABLE_COMPACT (2 << 8) /* OR into table_bits: 16-byte entries with 8-base keys (n < 2^24) */
 int genie_index_create_ex(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t dir_bits,

@@ -650,8 +650,8 @@ def test_absent_base_is_flagged(pkg):
 def test_report_helpers(pkg):
     """genie_search_kernel_name / genie_launch_info: what bench.py and the profile summaries key on."""
     ix = _index(pkg, "syn10k_K8")
-    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, false, false>"     # 32-byte entries: the table fits an XCD's L2
-    assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel<false>"
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, true, false>"      # <waves per SIMD, compact table, packed reads>
+    assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel<true>"
     info = ix.launch_info("lut", 150)
     assert info["block"] == 512 and 0 < info["lds_bytes"] <= 160 * 1024 and info["grid"] > 0
     # the stage switches are ignored unless the search kernel runs alone
@@ -784,6 +784,20 @@ def test_one_megabase_reference(pkg, oracle_mod):
             counts, want = o.find_smems_batch(algo, rd, nthreads=16)
             for i in range(len(rd)):
                 assert rows[i].tolist() == want[i, :counts[i]].tolist(), (kind, algo, i)
+    # the 32-byte form at this size (8 MB table: the two-blocks-per-CU instance of the kernel)
+    ixw = pkg.GenieIndex.build(ref, 15, table_format="wide")
+    ixw.set_rmi([1000], coefs, icpts)
+    ixw = ixw.to("cuda")
+    assert ixw.search_kernel_name("rmi", 150) == "match_table_kernel<4, false, false>"
+    rd = B.reads_from_ref(ref, 1500, 150, 1007)
+    for algo in ("bwa", "rmi"):
+        offsets, smems, st = ixw.find_smems(algo, rd)
+        assert int(st.abs().sum().item()) == 0
+        rows = _rows_per_read(offsets, smems)
+        counts, want = o.find_smems_batch(algo, rd, nthreads=16)
+        for i in range(len(rd)):
+            assert rows[i].tolist() == want[i, :counts[i]].tolist(), ("wide", algo, i)
+    del ixw
     rng = np.random.default_rng(9)
     pats = np.zeros((2000, 60), np.uint8)
     lens = rng.integers(1, 61, 2000).astype(np.int32)
@@ -967,20 +981,21 @@ def test_config4_eighty_million_reads_in_eight_shards(pkg, oracle_mod):
     assert total_reads == 80_000_000 and 8 * total_reads < total_rows < 16 * total_reads
 
 
-# ------------------------------------------------------------------ the compact match table on the small fixtures
+# ------------------------------------------------------------------ both forms of the match table on the small fixtures
+@pytest.mark.parametrize("fmt", ["wide", "compact"])
 @pytest.mark.parametrize("ds", [d for d in G.DATASETS if G.have(d)])
-def test_compact_table_golden_and_oracle(pkg, oracle_mod, ds):
-    """The compact (16-byte entry, 8-base key) match table is what references of more than ~260 kb get; here it is
-    forced on the golden datasets: every golden group's ordered rows against the reference's own outputs, and fresh
-    reads (from-ref, random, long exact copies of the reference, low complexity, ragged lengths, 256 .. 3000 bases)
-    against the CPU oracle, with the sampled and the every-position lookup."""
+def test_table_forms_golden_and_oracle(pkg, oracle_mod, ds, fmt):
+    """The match table has two forms (genie_internal.h): compact 16-byte entries with 8-base keys (the default below 2^24
+    bases) and 32-byte entries with 16-base keys.  Each is forced on the golden datasets: every golden group's ordered
+    rows against the reference's own outputs, and fresh reads (from-ref, random, long exact copies of the reference,
+    low complexity, ragged lengths, 1500 bases) against the CPU oracle, with the sampled and the every-position lookup."""
     import torch
     d, _ = G.load(ds)
     ref, K = d["ref_codes"], int(d["K"])
-    ix = pkg.GenieIndex.build(ref, K, table_format="compact")
+    ix = pkg.GenieIndex.build(ref, K, table_format=fmt)
     coefs, icpts, _, _, _ = ix.train_rmi([10, 100] if ds.startswith("medium") else [1000])
     ix = ix.to("cuda")
-    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, true, false>"
+    assert ix.search_kernel_name("lut", 150) == ("match_table_kernel<8, true, false>" if fmt == "compact" else "match_table_kernel<8, false, false>")
     for dsg, tag, algo in G.group_cases():
         if dsg != ds or algo == "rmi":
             continue

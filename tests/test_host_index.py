@@ -494,9 +494,8 @@ def test_compact_match_table_against_brute_force(pkg, case):
             want = [row for row, st in enumerate(sa0) if s[st:st + t] == mer[:t]]
             last = int(raw["key"][c][0]) | int(raw["key"][c][1]) << 16
             assert (int(lb[c]), last) == (want[0], want[-1]) and len(want) == want[-1] - want[0] + 1, mer
-    # the form is chosen by the size of the 32-byte table (4 MB = an XCD's L2) unless the caller asks
-    small = _parse(pkg.GenieIndex.build(ref, 6).serialize().numpy())
-    assert small["flags"] & 2 == 0 and small["ov_entries"] == 0
+    # compact is the default form
+    assert _parse(pkg.GenieIndex.build(ref, 6).serialize().numpy())["flags"] & 2
 
 
 def test_corrupt_image_is_rejected(pkg):
