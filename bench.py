@@ -58,6 +58,9 @@ CONFIGS = {
             L=150, mode="rmi", read_seed=1004, scaling="weak"),
     4: dict(name="1 Mb reference, 80M x 150 bp reads query-sharded over the GPUs, RMI-SMEM", ref="1Mb", n=1_000_000,
             ref_seed=1_000_000, reads=80_000_000, L=150, mode="rmi", read_seed=1005, scaling="strong"),
+    # not a BASELINE config: the size of the reference's own data/full_data.fa (SURVEY: the reference cannot index it)
+    5: dict(name="[off-BASELINE] 2.5 Mb reference (size of the reference's full_data.fa), 4M x 150 bp reads, RMI-SMEM", ref="2.5Mb",
+            n=2_499_750, ref_seed=2_499_750, reads=4_000_000, L=150, mode="rmi", read_seed=1006, scaling="weak"),
 }
 K = 15
 EXPERTS = [1000]
@@ -80,12 +83,16 @@ def gen_reads(ref_dev, n, L, seed, piece, read_kind="fromref"):
 
 
 def build_index(cfg, device):
+    """Native index build + RMI training (genie_index_create / genie_index_train_rmi); the device gets the image
+    WITHOUT the K-mer hash table (GENIE_IMAGE_NO_SEED_TABLE): nothing in find_smems reads it, and it is what a
+    multi-GPU run broadcasts."""
     ref = synth.synth_ref(cfg["n"], cfg["ref_seed"])
-    m = g.ExactMatch(f"REF_{cfg['n']}.fa", device=str(device))
-    m.set_reference("".join("ACGT"[c] for c in ref))
-    rl = g.RMI_LUT(EXPERTS, K, m.ref_seq_file, matcher=m)
-    rl.train_RMI()
-    return ref, rl._index(), rl
+    ix = g.GenieIndex.build(ref, K)
+    coefs, icpts, _, _, _ = ix.train_rmi(EXPERTS)
+    full_bytes = int(ix.serialize().numel())
+    ix._host_blob = None
+    ix.to(device, seed_table=False)
+    return ref, ix, {"coefs": coefs, "icpts": icpts, "full_image_bytes": full_bytes}
 
 
 def cpu_baseline(ref, cfg, rl, mode, sample_reads):
@@ -97,8 +104,7 @@ def cpu_baseline(ref, cfg, rl, mode, sample_reads):
     nproc = os.cpu_count() or 1
     threads = nproc                                  # all host cores (and one thread, below)
     o = orc.Oracle(ref, K)
-    coefs, icpts = rl.rmi.coefficients()
-    o.set_rmi(EXPERTS, coefs, icpts)
+    o.set_rmi(EXPERTS, rl["coefs"], rl["icpts"])
     rd = synth.reads_from_ref_fast(ref, sample_reads, cfg["L"], cfg["read_seed"])
     o.find_smems_batch(mode, rd[:2000], nthreads=threads)               # warm-up
     t0 = time.perf_counter()
@@ -465,7 +471,8 @@ def main():
                        "read_distribution": "from-ref segments U{1..30}" if args.read_kind == "fromref" else "uniform random",
                        **par,
                        "smems_per_read": round(w["all_rows"] / w["all_reads"], 3), "launch": ix.launch_info(mode, L), "counters_key": key,
-                       "index_build_s": round(w["t_build"], 3), "index_image_bytes": w["image_bytes"]},
+                       "index_build_s": round(w["t_build"], 3), "index_image_bytes": w["image_bytes"],
+                       "index_image_note": "image without the K-mer hash table (find_smems does not read it)"},
             "roofline": roof,
         }
         lib = g._native.lib()

@@ -21,6 +21,7 @@ MAX_K = 16
 MAX_READ_LEN = 8192
 MODE_BWA, MODE_LUT, MODE_RMI = 0, 1, 2
 MODES = {"bwa": MODE_BWA, "lut": MODE_LUT, "rmi": MODE_RMI}
+IMAGE_NO_SEED_TABLE = 1
 TABLE_WIDE, TABLE_COMPACT = 1 << 8, 2 << 8        # genie_index_create_ex: ORed into table_bits
 OPT_SEARCH_ALL = 2
 OPT_GROUP_POSITIONS = 4
@@ -33,7 +34,7 @@ READ_OK, READ_BAD_BASE, READ_TOO_SHORT, READ_ABSENT_BASE, READ_OVERFLOW = 0, 1, 
 SYMBOLS = [
     "genie_abi_version", "genie_index_create", "genie_index_create_from_sa", "genie_index_create_ex", "genie_index_set_rmi",
     "genie_index_info", "genie_index_suffix_array", "genie_index_lut_arrays", "genie_index_blob_bytes",
-    "genie_index_serialize", "genie_index_open", "genie_index_to_device", "genie_index_destroy",
+    "genie_index_serialize", "genie_index_image_bytes", "genie_index_serialize_image", "genie_index_open", "genie_index_validate", "genie_index_to_device", "genie_index_destroy",
     "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_csr", "genie_find_smems_packed", "genie_find_smems_workspace_bytes", "genie_find_smems_workspace_rows",
     "genie_compact_tmp_bytes",
     "genie_compact_smems", "genie_locate_tmp_bytes", "genie_locate", "genie_index_train_rmi", "genie_index_rmi_models", "genie_launch_info", "genie_search_kernel_name", "genie_index_set_option", "genie_index_set_stage_events", "genie_strerror", "genie_last_hip_error",
@@ -92,7 +93,10 @@ def lib():
         "genie_index_lut_arrays": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(i32p), C.POINTER(i32p)]),
         "genie_index_blob_bytes": (i64, [vp]),
         "genie_index_serialize": (C.c_int, [vp, vp, i64]),
+        "genie_index_image_bytes": (i64, [vp, i32]),
+        "genie_index_serialize_image": (C.c_int, [vp, i32, vp, i64]),
         "genie_index_open": (C.c_int, [vp, vp, i64, i32, vpp]),
+        "genie_index_validate": (C.c_int, [vp, C.POINTER(C.c_uint32), vp]),
         "genie_index_to_device": (C.c_int, [vp, i32]),
         "genie_index_destroy": (None, [vp]),
         "genie_sa_interval": (C.c_int, [vp, vp, vp, i64, i32, i32, vp, vp]),

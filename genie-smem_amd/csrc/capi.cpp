@@ -41,6 +41,8 @@ int make_index(const uint8_t *codes, int64_t n, const int32_t *sa1, int32_t K, i
 
 }  // namespace
 
+static int ready(const genie_index *ix);
+
 extern "C" {
 
 int genie_abi_version(void) { return GENIE_ABI_VERSION; }
@@ -164,6 +166,20 @@ int genie_index_serialize(const genie_index *ix, void *host_dst, int64_t cap)
     return serialize(*ix->host, host_dst, cap);
 }
 
+int64_t genie_index_image_bytes(const genie_index *ix, int32_t image_flags)
+{
+    if (!ix || !ix->host || (image_flags & ~GENIE_IMAGE_NO_SEED_TABLE)) return (int64_t)GENIE_E_INVALID;
+    BlobHeader hdr;
+    fill_header(*ix->host, &hdr, image_flags);
+    return hdr.total_bytes;
+}
+
+int genie_index_serialize_image(const genie_index *ix, int32_t image_flags, void *host_dst, int64_t cap)
+{
+    if (!ix || !ix->host || (image_flags & ~GENIE_IMAGE_NO_SEED_TABLE)) return GENIE_E_INVALID;
+    return serialize(*ix->host, host_dst, cap, image_flags);
+}
+
 int genie_index_open(const void *host_header, const void *d_blob, int64_t blob_bytes, int32_t device,
                      genie_index **ix_inout)
 {
@@ -187,6 +203,16 @@ int genie_index_open(const void *host_header, const void *d_blob, int64_t blob_b
     ix->num_cus = query_cus(device);
     *ix_inout = ix;
     return GENIE_OK;
+}
+
+int genie_index_validate(const genie_index *ix, uint32_t *what, void *stream)
+{
+    int rc = ready(ix);
+    if (rc) return rc;
+    unsigned int w = 0;
+    rc = validate_image(ix, &w, stream);
+    if (what) *what = w;
+    return rc;
 }
 
 int genie_index_to_device(genie_index *ix, int32_t device)
@@ -244,6 +270,7 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
     if (rc) return rc;
     if (N < 0 || (N > 0 && (!d_kmers || !d_out_lohi))) return GENIE_E_INVALID;
     if (ix->dev.K < 1) return GENIE_E_NO_LUT;
+    if (mode == GENIE_MODE_LUT && (ix->dev.flags & kFlagNoSeedTable)) return GENIE_E_NO_LUT;     // a find_smems-only image
     if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
     return launch_seed_lookup(ix, mode, d_kmers, N, d_out_lohi, d_pred, stream);
 }
@@ -390,7 +417,7 @@ const char *genie_strerror(int status)
     case GENIE_E_TOO_LONG: return "read longer than the kernel supports";
     case GENIE_E_NO_MODEL: return "no RMI model installed";
     case GENIE_E_BAD_BLOB: return "not a serialized GENIE index";
-    case GENIE_E_NO_LUT: return "index built without a K-mer table (K = 0)";
+    case GENIE_E_NO_LUT: return "no K-mer table (index built with K = 0, or an image serialized without its seed table)";
     case GENIE_E_CAPACITY: return "output capacity too small";
     case GENIE_W_SEARCH_ONLY: return "GENIE_OPT_SEARCH_ONLY is set: no outputs were produced";
     default: return "unknown status";

@@ -97,6 +97,7 @@ struct MatchOv16 {
     uint16_t key[kM16OvKeys];
 };
 constexpr int64_t kM16MaxN = (int64_t)1 << 24;
+constexpr int32_t kFlagNoSeedTable = 4;        // the image carries no K-mer hash table (find_smems-only image): genie_seed_lookup(LUT) refuses
 constexpr int32_t kFlagCompactTable = 2;       // BlobHeader.flags / DevIndex.flags: mtab holds MatchRec16 entries
 constexpr int64_t kTableFitsL2 = 4ll << 20;    // bytes of table an XCD's L2 keeps
 
@@ -235,8 +236,9 @@ struct HostIndex {
 // 2 = compact entries
 int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_based, int32_t K, int32_t P,
                      int32_t dir2_bits, int32_t table_format, HostIndex **out);
-void fill_header(const HostIndex &h, BlobHeader *hdr);
-int serialize(const HostIndex &h, void *dst, int64_t cap);
+// image_flags: GENIE_IMAGE_* (genie_smem.h)
+void fill_header(const HostIndex &h, BlobHeader *hdr, int32_t image_flags = 0);
+int serialize(const HostIndex &h, void *dst, int64_t cap, int32_t image_flags = 0);
 int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t bytes, DevIndex *out);
 
 }  // namespace genie
@@ -289,6 +291,7 @@ int find_smems_geometry(const genie_index *ix, int32_t mode, int32_t max_len, in
                         int32_t *lds_bytes);
 void find_smems_workspace_rows(int32_t max_len, int32_t out[4]);
 int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, char *buf, int32_t cap);
+int validate_image(const genie_index *ix, unsigned int *what, void *stream);
 void set_hip_error(const char *what, int code);
 const char *last_hip_error();
 }  // namespace genie

@@ -370,8 +370,9 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
 
 static int64_t align_up(int64_t x) { return (x + kSectionAlign - 1) / kSectionAlign * kSectionAlign; }
 
-void fill_header(const HostIndex &h, BlobHeader *hdr)
+void fill_header(const HostIndex &h, BlobHeader *hdr, int32_t image_flags)
 {
+    const bool no_seed = (image_flags & GENIE_IMAGE_NO_SEED_TABLE) != 0;
     memset(hdr, 0, sizeof(*hdr));
     hdr->magic = kMagic;
     hdr->version = kBlobVersion;
@@ -381,11 +382,11 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->P = h.P;
     hdr->ref_recs = (int64_t)h.ref.size();
     hdr->dir_entries = (int64_t)h.dir.size();
-    hdr->lut_slots = (int64_t)h.lut_slots.size();
+    hdr->lut_slots = no_seed ? 8 : (int64_t)h.lut_slots.size();
     hdr->lut_keys = (int64_t)h.lut_code.size();
     hdr->rmi_models = (int64_t)h.rmi.size();
     hdr->P2 = h.P2;
-    hdr->flags = h.flags;
+    hdr->flags = h.flags | (no_seed ? kFlagNoSeedTable : 0);
     hdr->dir2_entries = (int64_t)h.dir2.size();
     hdr->nlev = h.nlev;
     for (int l = 0; l < GENIE_MAX_RMI_LEVELS; l++) {
@@ -402,7 +403,7 @@ void fill_header(const HostIndex &h, BlobHeader *hdr)
     hdr->off_dir = off;
     off = align_up(off + (int64_t)h.dir.size() * 4);
     hdr->off_lut = off;
-    off = align_up(off + (int64_t)h.lut_slots.size() * (int64_t)sizeof(LutSlot));
+    off = align_up(off + hdr->lut_slots * (int64_t)sizeof(LutSlot));
     hdr->off_rmi = off;
     off = align_up(off + (int64_t)std::max<size_t>(h.rmi.size(), 1) * (int64_t)sizeof(RmiModel));
     hdr->off_dir2 = off;
@@ -556,10 +557,10 @@ int train_rmi(HostIndex &h, int n_experts, const int32_t *experts, double *mean_
     return GENIE_OK;
 }
 
-int serialize(const HostIndex &h, void *dst, int64_t cap)
+int serialize(const HostIndex &h, void *dst, int64_t cap, int32_t image_flags)
 {
     BlobHeader hdr;
-    fill_header(h, &hdr);
+    fill_header(h, &hdr, image_flags);
     if (!dst || cap < hdr.total_bytes) return GENIE_E_INVALID;
     uint8_t *p = (uint8_t *)dst;
     memset(p, 0, (size_t)hdr.total_bytes);
@@ -567,7 +568,12 @@ int serialize(const HostIndex &h, void *dst, int64_t cap)
     memcpy(p + hdr.off_sa, h.sarec.data(), h.sarec.size() * sizeof(SaRec));
     memcpy(p + hdr.off_ref, h.ref.data(), h.ref.size() * sizeof(RefRec));
     memcpy(p + hdr.off_dir, h.dir.data(), h.dir.size() * 4);
-    memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
+    if (hdr.flags & kFlagNoSeedTable) {
+        const LutSlot empty{0, -1, -1, 0};
+        for (int64_t i = 0; i < hdr.lut_slots; i++) memcpy(p + hdr.off_lut + i * (int64_t)sizeof(LutSlot), &empty, sizeof(empty));
+    } else {
+        memcpy(p + hdr.off_lut, h.lut_slots.data(), h.lut_slots.size() * sizeof(LutSlot));
+    }
     if (!h.rmi.empty()) memcpy(p + hdr.off_rmi, h.rmi.data(), h.rmi.size() * sizeof(RmiModel));
     if (!h.dir2.empty()) memcpy(p + hdr.off_dir2, h.dir2.data(), h.dir2.size() * sizeof(HeadRec));
     if (!h.rmi_err.empty()) memcpy(p + hdr.off_rmi_err, h.rmi_err.data(), h.rmi_err.size() * 4);
@@ -617,7 +623,9 @@ int dev_index_from_header(const BlobHeader &hdr, const void *d_blob, int64_t byt
         !section_ok(hdr, bytes, hdr.off_ov, hdr.ov_entries, sizeof(MatchOv16)))
         return GENIE_E_BAD_BLOB;
     // the hash table needs an empty slot for every probe sequence to end
-    if (hdr.lut_keys < 0 || hdr.lut_slots < hdr.lut_keys + 1 || hdr.lut_slots > 0xFFFFFFFFll) return GENIE_E_BAD_BLOB;
+    if (hdr.lut_keys < 0 || hdr.lut_slots > 0xFFFFFFFFll || hdr.lut_slots < 1 ||
+        (!(hdr.flags & kFlagNoSeedTable) && hdr.lut_slots < hdr.lut_keys + 1))
+        return GENIE_E_BAD_BLOB;
     // RMI level table: level l has rmi_size[l] models at rmi_off[l]; level l + 1 has rmi_scale[l] of them
     if (hdr.nlev < 0 || hdr.nlev > GENIE_MAX_RMI_LEVELS) return GENIE_E_BAD_BLOB;
     if (hdr.nlev > 0) {

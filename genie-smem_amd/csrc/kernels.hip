@@ -1096,6 +1096,85 @@ __global__ void __launch_bounds__(256) locate_scatter_kernel(DevIndex ix, const 
 
 }  // namespace
 
+// ------------------------------------------------------------------ image contents (genie_index_validate)
+namespace {
+
+// Every value of the image that a kernel later uses as a row number, an entry index or a suffix start is checked
+// against the section sizes, so that a corrupt or stale image cannot send a load outside the image.  (What the rows
+// MEAN -- that the suffix array is sorted, that keys belong to their rows -- is not checked: a wrong table gives wrong
+// answers, not wild accesses.)
+__global__ void __launch_bounds__(256) validate_image_kernel(DevIndex ix, unsigned int *__restrict__ bad)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long rows = (long long)ix.n + 1;
+    unsigned int err = 0;
+    for (long long r = t0; r < rows; r += stride) {
+        const int s = ix.sa[r].s;
+        err |= (s < 0 || s > ix.n) ? 1u : 0u;
+    }
+    for (long long x = t0; x < ix.dir_entries; x += stride) {
+        const uint32_t v = ix.dir[x];
+        err |= (v > (uint32_t)rows || (x + 1 < ix.dir_entries && v > ix.dir[x + 1])) ? 2u : 0u;
+    }
+    const long long nb2 = 1ll << (2 * ix.P2);
+    for (long long c = t0; c < nb2; c += stride) {
+        const HeadRec h = ix.dir2[c];
+        err |= ((long long)h.lb + (h.meta & ~kHeadShort) > rows) ? 4u : 0u;
+        if (ix.flags & kFlagCompactTable) {
+            const MatchRec16 m = reinterpret_cast<const MatchRec16 *>(ix.mtab)[c];
+            const uint32_t lb = m.w0 & 0xFFFFFFu, cnt4 = (m.w0 >> 24) & 15u, nib = m.w0 >> 28;
+            if (cnt4 == 0) {
+                const uint32_t last = (uint32_t)m.key[0] | (uint32_t)m.key[1] << 16;
+                err |= (nib >= 1 && (lb > last || last > (uint32_t)ix.n)) ? 8u : 0u;
+            } else {
+                const uint32_t nrow = cnt4 == kM16More ? 7u + nib : cnt4;
+                err |= (cnt4 > kM16More || (long long)lb + nrow > rows) ? 8u : 0u;
+                err |= (cnt4 == kM16More && (nib > 6u || m.key[kM16Keys - 1] == 0 || (int)m.key[kM16Keys - 1] >= ix.ov_entries)) ? 16u : 0u;
+            }
+        } else {
+            const MatchRec m = ix.mtab[c];
+            const uint32_t nrow = m.meta >> 24;
+            if (nrow == 0) {
+                err |= ((m.meta & 0xFFu) >= 1 && (m.lb > m.key[0] || m.key[0] > (uint32_t)ix.n)) ? 8u : 0u;
+            } else {
+                err |= ((long long)m.lb + nrow > rows || (m.meta & 0xFFu) != (uint32_t)ix.P2) ? 8u : 0u;
+                if (m.meta & kMatchMore) {
+                    const long long idx = m.key[kMatchKeys - 1], extra = ((long long)nrow - (kMatchKeys - 1) + 7) >> 3;
+                    err |= (idx < nb2 || idx + extra > ix.mtab_entries) ? 16u : 0u;
+                }
+            }
+        }
+    }
+    for (long long i = t0; i < (long long)ix.lut_slots; i += stride) {
+        const LutSlot sl = ix.lut[i];
+        err |= (sl.lo >= 0 && (sl.lo > sl.hi || sl.hi > ix.n)) ? 32u : 0u;
+    }
+    if (ix.rmi_err && ix.nlev > 0)
+        for (long long i = t0; i < ix.rmi_off[ix.nlev] - ix.rmi_off[ix.nlev - 1]; i += stride) err |= ix.rmi_err[i] < 0 ? 64u : 0u;
+    if (err) atomicOr(bad, err);
+}
+
+}  // namespace
+
+int validate_image(const genie_index *ix, unsigned int *what, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *d_bad = nullptr, h_bad = 0;
+    HIP_TRY(hipMalloc(&d_bad, sizeof(unsigned int)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), s);
+    if (e == hipSuccess) {
+        const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
+        hipLaunchKernelGGL(validate_image_kernel, dim3((unsigned)cus * 8), dim3(256), 0, s, ix->dev, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) { set_hip_error("validate_image", (int)e); return GENIE_E_HIP; }
+    if (what) *what = h_bad;
+    return h_bad ? GENIE_E_BAD_BLOB : GENIE_OK;
+}
+
 int64_t locate_tmp_bytes(int64_t S) { return ws_align(S * 4) + ws_align(compact_tmp_bytes(S)) + 256; }
 
 int launch_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, int64_t S, int64_t *d_offsets,

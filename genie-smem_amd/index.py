@@ -124,8 +124,17 @@ class GenieIndex:
         return (np.ctypeslib.as_array(cp, (m,)), np.ctypeslib.as_array(lp, (m,)), np.ctypeslib.as_array(hp, (m,)))
 
     # ------------------------------------------------------------------ image / device
-    def serialize(self):
-        """The flat index image as a CPU uint8 tensor (header + sections)."""
+    def serialize(self, seed_table=True):
+        """The flat index image as a CPU uint8 tensor (header + sections).  seed_table=False leaves out the K-mer hash
+        table (GENIE_IMAGE_NO_SEED_TABLE): the image of a rank that only finds SMEMs."""
+        if not seed_table:
+            nbytes = N.lib().genie_index_image_bytes(self._h, N.IMAGE_NO_SEED_TABLE)
+            if nbytes <= 0:
+                raise N.GenieError(int(nbytes), "genie_index_image_bytes")
+            buf = torch.empty(nbytes, dtype=torch.uint8)
+            N.check(N.lib().genie_index_serialize_image(self._h, N.IMAGE_NO_SEED_TABLE, C.c_void_p(buf.data_ptr()), nbytes),
+                    "genie_index_serialize_image")
+            return buf
         if self._host_blob is None:
             nbytes = N.lib().genie_index_blob_bytes(self._h)
             if nbytes <= 0:
@@ -135,14 +144,14 @@ class GenieIndex:
             self._host_blob = buf
         return self._host_blob
 
-    def to(self, device):
+    def to(self, device, seed_table=True):
         """Upload the image with torch and bind it (torch owns the device memory)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("GenieIndex.to: an MI355X device is required (no CPU fallback)")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        host = self.serialize()
+        host = self.serialize(seed_table)
         self._bind(host.to(device), host[:N.HEADER_BYTES])
         return self
 
@@ -153,6 +162,14 @@ class GenieIndex:
                                          dev_blob.numel(), dev_index, C.byref(self._h)), "genie_index_open")
         self.blob = dev_blob
         self.device = dev_blob.device
+        if dev_blob.device.type == "cuda":
+            # the header was checked by open; the contents (row numbers, entry links) on the device, once
+            what = C.c_uint32(0)
+            with torch.cuda.device(self.device):
+                rc = N.lib().genie_index_validate(self._h, C.byref(what), _stream(self.device))
+            if rc:
+                self.blob = None
+                raise N.GenieError(rc, f"genie_index_validate (sections {what.value:#x})")
 
     @classmethod
     def from_image(cls, dev_blob):

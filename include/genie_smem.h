@@ -48,7 +48,7 @@ typedef enum genie_status {
     GENIE_E_TOO_LONG = -6,     /* read/pattern longer than GENIE_MAX_READ_LEN */
     GENIE_E_NO_MODEL = -7,     /* RMI mode requested but no model was set */
     GENIE_E_BAD_BLOB = -8,     /* serialized index: wrong magic / version / size */
-    GENIE_E_NO_LUT = -9,       /* LUT mode requested but the index was built with K = 0 */
+    GENIE_E_NO_LUT = -9,       /* LUT mode requested but the index was built with K = 0, or the image has no seed table */
     GENIE_E_CAPACITY = -10,    /* output buffer too small (compaction) */
     GENIE_W_SEARCH_ONLY = 1    /* GENIE_OPT_SEARCH_ONLY is set: only the match-statistics kernel was launched;
                                   counts / offsets / rows were NOT written */
@@ -145,12 +145,26 @@ int genie_index_lut_arrays(const genie_index *ix, const uint32_t **codes, const 
 int64_t genie_index_blob_bytes(const genie_index *ix);
 int genie_index_serialize(const genie_index *ix, void *host_dst, int64_t cap);
 
+/* The same with options.  GENIE_IMAGE_NO_SEED_TABLE leaves out the K-mer hash table (half of the image at 1 Mb): for ranks
+ * that only run genie_find_smems* / genie_sa_interval / genie_locate -- genie_seed_lookup(LUT) on such an image returns
+ * GENIE_E_NO_LUT.  (What a multi-GPU driver broadcasts.) */
+#define GENIE_IMAGE_NO_SEED_TABLE 1
+int64_t genie_index_image_bytes(const genie_index *ix, int32_t image_flags);
+int genie_index_serialize_image(const genie_index *ix, int32_t image_flags, void *host_dst, int64_t cap);
+
 /* Open a device-resident image.  `host_header` = the first GENIE_HEADER_BYTES of the same
  * image in host memory (ranks that received it by broadcast copy those bytes back).  The
  * image is NOT copied and must outlive the handle.  If `ix_inout` points at an existing handle
  * the image is bound to it (keeps the host arrays); otherwise a device-only handle is made. */
 int genie_index_open(const void *host_header, const void *d_blob, int64_t blob_bytes, int32_t device,
                      genie_index **ix_inout);
+
+/* Check the CONTENTS of an opened image on the device (genie_index_open checks the header only): every row number,
+ * entry index and suffix start that a kernel will later follow must lie inside its section.  One pass over the image on
+ * `stream`, then a synchronisation.  GENIE_E_BAD_BLOB when something is out of range (*what, optional, gets a bit per
+ * section: 1 suffix array, 2 prefix directory, 4 range table, 8 / 16 match table / its overflow links, 32 K-mer table,
+ * 64 RMI error bounds).  The drop-in calls it on every image it opens, also on one received by broadcast. */
+int genie_index_validate(const genie_index *ix, uint32_t *what, void *stream);
 
 /* Convenience for non-torch callers: hipMalloc + upload an image owned by the handle. */
 int genie_index_to_device(genie_index *ix, int32_t device);

@@ -1103,3 +1103,85 @@ def test_packed_entry_point_equals_csr(pkg, oracle_mod):
     bad[1, 5] = 7
     with pytest.raises(KeyError):
         packing.pack_reads(bad)
+
+
+def test_image_validation_and_seedless_image(pkg):
+    """genie_index_validate: an image whose CONTENTS point outside its sections (a suffix start beyond n, a match-table row
+    beyond the suffix array, an overflow link beyond the blocks) is refused when it is bound, for both table forms; the
+    image without the K-mer hash table finds SMEMs like the full one and refuses LUT seed lookups."""
+    import struct
+    import torch
+    from test_host_index import _parse
+    from genie_smem_amd import synth as B
+    ref = np.random.default_rng(8).integers(0, 4, 50_000).astype(np.uint8)
+    for fmt in ("compact", "wide"):
+        ix = pkg.GenieIndex.build(ref, 12, table_format=fmt)
+        img = ix.serialize().clone()
+        h = _parse(img.numpy())
+        assert pkg.GenieIndex.from_image(img.cuda()).n == len(ref)
+        esz = 16 if fmt == "compact" else 32
+        first_present = 11
+        edits = [(h["off_sa"] + 16 * 777, struct.pack("<i", len(ref) + 5)),                         # a suffix start beyond n
+                 (h["off_dir"] + 4 * 100, struct.pack("<I", len(ref) + 9)),                         # a directory entry beyond the rows
+                 (h["off_dir2"] + 16 * 5, struct.pack("<II", len(ref) - 1, 7))]                    # a range beyond the rows
+        if fmt == "compact":
+            edits.append((h["off_mtab"] + esz * first_present, struct.pack("<I", (len(ref) - 2) | (6 << 24))))     # 6 rows from n - 2
+            edits.append((h["off_mtab"] + esz * first_present, struct.pack("<I", 5 | (7 << 24)) + bytes(10) + struct.pack("<H", 60000)))   # overflow link
+        else:
+            edits.append((h["off_mtab"] + esz * first_present, struct.pack("<II", h["P2"] | (0x1F << 8) | (6 << 24), len(ref) - 2)))
+        for off, blob in edits:
+            bad = img.clone()
+            bad[off:off + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            with pytest.raises(pkg._native.GenieError) as e:
+                pkg.GenieIndex.from_image(bad.cuda())
+            assert e.value.status == -8, (fmt, off)
+    ix = pkg.GenieIndex.build(ref, 12)
+    ix.train_rmi([10])
+    full = pkg.GenieIndex.from_image(ix.serialize().cuda())
+    slim = pkg.GenieIndex.from_image(ix.serialize(seed_table=False).cuda())
+    assert slim.blob.numel() < full.blob.numel()
+    rd = B.reads_from_ref(ref, 300, 120, 2)
+    for mode in ("bwa", "lut", "rmi"):
+        a, b = full.find_smems(mode, rd), slim.find_smems(mode, rd)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    km = rd[:50, :12]
+    assert torch.equal(full.seed_lookup("rmi", km), slim.seed_lookup("rmi", km))
+    full.seed_lookup("lut", km)
+    with pytest.raises(pkg._native.GenieError) as e:
+        slim.seed_lookup("lut", km)
+    assert e.value.status == -9
+
+
+# ------------------------------------------------------------------ beyond the BASELINE sizes
+def test_two_and_a_half_megabase_reference(pkg, oracle_mod):
+    """A reference of the size of the reference's own data/full_data.fa (2 499 750 bases -- the one its README says it
+    cannot index): synthetic bases, K = 15, natively trained RMI [1000], a 16 MB compact table that no XCD's L2 holds.
+    3 000 from-ref and 1 000 random reads, three modes, row by row against the CPU oracle; exact-match patterns too."""
+    from genie_smem_amd import synth as B
+    n = 2_499_750
+    ref = B.synth_ref(n, n)
+    ix = pkg.GenieIndex.build(ref, 15)
+    coefs, icpts, _, _, _ = ix.train_rmi([1000])
+    ix = ix.to("cuda", seed_table=False)
+    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<4, true, false>"      # the table exceeds an XCD's L2
+    o = oracle_mod.Oracle(ref, 15)
+    o.set_rmi([1000], coefs, icpts)
+    for kind, rd in (("fromref", B.reads_from_ref(ref, 3000, 150, 2501)), ("random", B.reads_random(1000, 150, 2502))):
+        for algo in ("bwa", "lut", "rmi"):
+            offsets, smems, st = ix.find_smems(algo, rd)
+            assert int(st.abs().sum().item()) == 0
+            rows = _rows_per_read(offsets, smems)
+            counts, want = o.find_smems_batch(algo, rd, nthreads=16)
+            for i in range(len(rd)):
+                assert rows[i].tolist() == want[i, :counts[i]].tolist(), (kind, algo, i)
+    rng = np.random.default_rng(10)
+    pats = np.zeros((1500, 60), np.uint8)
+    lens = rng.integers(1, 61, 1500).astype(np.int32)
+    for i in range(1500):
+        p0 = int(rng.integers(0, n - 60))
+        pats[i, :lens[i]] = ref[p0:p0 + lens[i]]
+        if i % 3 == 0:
+            pats[i, lens[i] - 1] = (pats[i, lens[i] - 1] + 1) % 4
+    got = ix.sa_interval(pats, lens).cpu().numpy()
+    for i in range(1500):
+        assert tuple(got[i]) == o.back_prop(pats[i, :lens[i]]), i

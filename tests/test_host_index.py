@@ -545,3 +545,24 @@ def test_corrupt_image_is_rejected(pkg):
                 dict(rmi_err_entries=h["rmi_err_entries"] + 1), dict(P2=h["P"]), dict(P2=13),
                 dict(mtab_entries=h["dir2_entries"] - 1), dict(mtab_entries=1 << 27), dict(dir2_entries=4), dict(ref_recs=1), dict(version=6)):
         assert corrupt(**bad) == -8, bad
+
+
+def test_image_without_seed_table(pkg):
+    """GENIE_IMAGE_NO_SEED_TABLE: the same image minus the K-mer hash table; it opens, says so in its flags, and every
+    other section is byte-identical."""
+    import ctypes as C
+    ref = np.random.default_rng(3).integers(0, 4, 20_000).astype(np.uint8)
+    ix = pkg.GenieIndex.build(ref, 12)
+    ix.train_rmi([10])
+    full, slim = ix.serialize().numpy(), ix.serialize(seed_table=False).numpy()
+    hf, hs = _parse(full), _parse(slim)
+    assert hs["lut_slots"] == 8 and hf["lut_slots"] > 2 * hf["lut_keys"] > 16 and hs["lut_keys"] == hf["lut_keys"]
+    assert hs["flags"] == hf["flags"] | 4 and len(slim) < len(full) - 16 * (hf["lut_slots"] - 8) + 512
+    for name, size in (("off_sa", 16 * (len(ref) + 1)), ("off_dir", 4 * hf["dir_entries"]), ("off_dir2", 16 * hf["dir2_entries"]),
+                       ("off_mtab", 16 * hf["mtab_entries"]), ("off_ov", 16 * hf["ov_entries"]), ("off_rmi", 16 * hf["rmi_models"])):
+        assert bytes(full[hf[name]:hf[name] + size]) == bytes(slim[hs[name]:hs[name] + size]), name
+    out = C.c_void_p(None)
+    lib = pkg._native.lib()
+    assert lib.genie_index_open(slim.ctypes.data_as(C.c_void_p), C.c_void_p(0x7f0000000000), len(slim), 0, C.byref(out)) == 0
+    lib.genie_index_destroy(out)
+    assert lib.genie_index_image_bytes(ix._h, 2) == -1 and lib.genie_index_image_bytes(ix._h, 1) == len(slim)
