@@ -4,7 +4,7 @@
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-from-host"
+B="--no-cpu-baseline --no-from-host --no-other-configs"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O -o kt --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 $B "$@" > $O/kt_bench.json 2> $O/kt.err || { tail -3 $O/kt.err; exit 1; }
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
