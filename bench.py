@@ -121,6 +121,32 @@ def cpu_baseline(ref, cfg, rl, mode, sample_reads):
                       f"OpenMP over reads, {dt:.2f} s wall"}, rd, counts, rows
 
 
+def bind_to_gpu_numa(device):
+    """Best effort: run this process (and so place its pinned buffers) on the NUMA node the GPU hangs off; the from-host
+    rate is a host-link measurement and varies several-fold with where the pinned pages live.  Returns the node or None."""
+    try:
+        bdf = None
+        props = torch.cuda.get_device_properties(device)
+        if hasattr(props, "pci_bus_id") and hasattr(props, "pci_device_id"):
+            bdf = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        if bdf is None or not os.path.exists(f"/sys/bus/pci/devices/{bdf}/numa_node"):
+            return None
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            return node
+    except Exception:  # noqa: BLE001 - measurement hygiene only
+        pass
+    return None
+
+
 def from_host_rate(lib, ix, mode_id, host_reads, L, rows_per_read, steps=9, packed=True):
     """Section 8(d)'s metric as SURVEY words it: pinned host reads -> H2D -> the call -> D2H of the results, a
     three-stage pipeline (copy-in, kernels, copy-out streams) over three buffers.  The host link sets this rate; it is never `value`.
@@ -482,6 +508,8 @@ def main():
         }
         lib = g._native.lib()
         if world == 1 and not args.no_from_host and n_reads <= 2_000_000 and L <= 255:
+            saved_affinity = os.sched_getaffinity(0)
+            node = bind_to_gpu_numa(device)
             host_reads = w["reads"].cpu().pin_memory()
             v, ms, bpr = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=True)
             v0, ms0, bpr0 = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=False)
@@ -491,6 +519,8 @@ def main():
                                                "host-link bound; never `value`)",
                                        "unpacked": {"value": v0, "ms_per_step": ms0, "link_bytes_per_read": round(bpr0, 1),
                                                     "what": "the same through genie_find_smems_csr: a byte per base in, int64 offsets + 16-byte rows out"}}
+            line["value_from_host"]["numa_node_bound"] = node
+            os.sched_setaffinity(0, saved_affinity)
             del host_reads
         if not args.no_cpu_baseline and world == 1:
             base, rd_s, cnt_s, rows_s = cpu_baseline(w["ref_codes"], cfg, w["rl"], mode, args.cpu_sample)

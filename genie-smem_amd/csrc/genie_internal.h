@@ -80,11 +80,16 @@ static_assert(sizeof(MatchRec) == 32, "MatchRec must be one 32-byte fetch");
 //                          are the suffix-array rows of that prefix
 //   key[i]  the 8 bases that follow the first P2 bases of suffix-array row lb + i, packed like the reference (base j in
 //           bits [14-2j, 15-2j]); ascending.
+//   WIDE KEYS: an entry of one to three suffixes, none cut short within P2 + 16 bases, spends its twelve key bytes on
+//           three 32-bit keys of 16 bases instead (nib = kM16Wide; dwords 1..3; unused slots repeat the first): most
+//           lookups on a small reference land on such entries, and a key that is exhausted after 8 bases costs two more
+//           requests (the rows) where one of 16 bases decides.
 // A match that exhausts a key (P2 + 8 bases, more of the read left) is decided by the suffix-array rows whose keys
 // agree (inline 32-base key, then the packed reference).
 constexpr int kM16Keys = 6;
 constexpr uint32_t kM16More = 7;
 constexpr uint32_t kM16General = 8;
+constexpr uint32_t kM16Wide = 4;
 constexpr int kM16OvKeys = 8;                                  // keys per overflow block
 constexpr int kM16MaxRows = kM16Keys - 1 + kM16OvKeys;         // 13: the most suffixes an entry + its block describe
 constexpr int64_t kM16MaxOv = 65536;                           // overflow blocks a 16-bit index reaches

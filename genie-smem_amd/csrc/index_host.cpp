@@ -199,6 +199,7 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
             }
             std::vector<uint32_t> cnt((size_t)nb2, 0), first((size_t)nb2, 0), ovf(compact ? (size_t)nb2 : 0, 0);
             std::vector<uint8_t> cut((size_t)nb2, 0);                   // a suffix of the entry has fewer than P2 + KB bases
+            std::vector<uint8_t> cut16(compact ? (size_t)nb2 : 0, 0);   // ... fewer than P2 + 16 (compact form: no wide keys)
             for (int64_t r = 0; r < rows; r++) {
                 const int64_t s = h->sa0[(size_t)r];
                 if (n - s < P2) continue;
@@ -213,6 +214,7 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                 e.meta++;
                 cnt[(size_t)c]++;
                 if (n - s < P2 + KB) cut[(size_t)c] = 1;
+                if (compact && n - s < P2 + 16) cut16[(size_t)c] = 1;
             }
             // keys: up to kMatchKeys in the entry itself; kMatchKeys+1 .. kMatchChainRows rows: kMatchKeys-1 in the
             // entry, its last slot = index of the overflow entries (8 keys each) appended behind the table.
@@ -222,13 +224,20 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                 if (n - s < P2) continue;
                 const uint64_t c = code_at64(codes, s, P2);
                 const uint32_t rows_c = cnt[(size_t)c], k = (uint32_t)r - first[(size_t)c];
-                uint32_t key = 0;
-                for (int j = 0; j < KB; j++) {
+                uint32_t key = 0, key32 = 0;
+                for (int j = 0; j < 16; j++) {
                     const int64_t p = s + P2 + j;
-                    key |= (p < n ? (uint32_t)codes[p] : 0u) << (2 * (KB - 1 - j));
+                    key32 |= (p < n ? (uint32_t)codes[p] : 0u) << (30 - 2 * j);
                 }
+                key = compact ? key32 >> 16 : key32;                      // the first KB bases
                 if (compact) {
                     MatchRec16 &m = h->mtab16[(size_t)c];
+                    if (rows_c <= 3u && !cut16[(size_t)c]) {                 // wide keys: three 32-bit keys in dwords 1..3
+                        uint32_t *k32 = reinterpret_cast<uint32_t *>(m.key);
+                        if (k == 0) k32[0] = k32[1] = k32[2] = key32;
+                        k32[k] = key32;
+                        continue;
+                    }
                     const bool block = !cut[(size_t)c] && rows_c > (uint32_t)kM16Keys && rows_c <= (uint32_t)kM16MaxRows;
                     if (k == 0) {
                         for (int j = 0; j < kM16Keys; j++) m.key[j] = (uint16_t)key;                 // unused slots repeat key[0]
@@ -306,6 +315,8 @@ int build_host_index(const uint8_t *codes, int64_t n, const int32_t *sa_one_base
                         m.w0 = plb | ((uint32_t)t << 28);
                         m.key[0] = (uint16_t)(plast & 0xFFFFu);
                         m.key[1] = (uint16_t)(plast >> 16);
+                    } else if (k <= 3u && !cut16[(size_t)c]) {
+                        m.w0 = first[(size_t)c] | (k << 24) | (kM16Wide << 28);
                     } else if (k <= (uint32_t)kM16Keys) {
                         m.w0 = first[(size_t)c] | (k << 24) | ((cut[(size_t)c] ? kM16General : 0u) << 28);
                     } else if (ovf[(size_t)c]) {                          // 7 .. 13 suffixes, none cut short: five keys + a block

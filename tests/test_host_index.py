@@ -451,10 +451,10 @@ def test_compact_match_table_against_brute_force(pkg, case):
     occ = [set()] + [{s[i:i + t] for i in range(n - t + 1)} for t in range(1, P2 + 1)]
     sa0 = ix.suffix_array().astype(np.int64) - 1
 
-    def key_of(st):
+    def key_of(st, nb=8):
         k = 0
-        for j in range(8):
-            k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (14 - 2 * j)
+        for j in range(nb):
+            k |= (int(ref[st + P2 + j]) if st + P2 + j < n else 0) << (2 * (nb - 1 - j))
         return k
 
     by_code, first_row = {}, {}
@@ -463,7 +463,7 @@ def test_compact_match_table_against_brute_force(pkg, case):
             by_code.setdefault(s[st:st + P2], []).append(int(st))
             first_row.setdefault(s[st:st + P2], row)
     code_of = lambda t: int("".join(str("ACGT".index(c)) for c in t), 4)        # noqa: E731
-    blocks, many = set(), 0
+    blocks, many, wide = set(), 0, 0
     for mer, starts in by_code.items():
         c = code_of(mer)
         keys = [key_of(st) for st in starts]
@@ -471,7 +471,11 @@ def test_compact_match_table_against_brute_force(pkg, case):
         cut = any(n - st < P2 + 8 for st in starts)
         assert lb[c] == first_row[mer]
         assert cut or keys == sorted(keys)
-        if 7 <= k <= 13 and not cut:
+        if k <= 3 and not any(n - st < P2 + 16 for st in starts):            # wide keys: three 16-base keys in the twelve bytes
+            wide += 1
+            k32 = [key_of(st, 16) for st in starts]
+            assert cnt4[c] == k and nib[c] == 4 and raw["key"][c].view("<u4").tolist() == k32 + [k32[0]] * (3 - k), mer
+        elif 7 <= k <= 13 and not cut:
             assert cnt4[c] == 7 and nib[c] == k - 7 and raw["key"][c][:5].tolist() == keys[:5], mer
             b = int(raw["key"][c][5])
             assert 1 <= b < h["ov_entries"] and b not in blocks
@@ -481,6 +485,7 @@ def test_compact_match_table_against_brute_force(pkg, case):
             many += k > 13
             assert cnt4[c] == min(k, 6) and nib[c] == (8 if cut or k > 6 else 0), mer
             assert raw["key"][c].tolist() == ((keys + [keys[0]] * 6)[:6] if k <= 6 else keys[:6]), mer
+    assert wide > 0 or case == "tiny"                           # (13 bases: every suffix is cut short)
     assert len(blocks) == h["ov_entries"] - 1
     if case == "repeat":
         assert len(blocks) >= 5 and many >= 1
