@@ -214,19 +214,23 @@ def from_host_rate(lib, ix, mode_id, host_reads, L, rows_per_read, steps=9, pack
                 self.h_rows.copy_(self.rows, non_blocking=True)
                 self.ev_out.record(s_out)
 
-    s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     nbuf = int(os.environ.get("GENIE_BENCH_NBUF", "3"))
     bufs = [Buf() for _ in range(nbuf)]
-    # Steady state of long-lived pinned buffers: the first few hundred MB of DMA into freshly pinned pages run at half
-    # the rate (tools/experiments/pipeline_probe.py: 3.9 ms per step, then 2.2 ms on the same buffers), so a whole
-    # untimed round precedes the timed one.
+    # Two rounds, each on its own three streams, the faster one reported (both recorded): the first stream set a process
+    # creates ran the same pipeline at half the rate of every later one (tools/experiments/pipeline_probe.py: 3.93 ms per
+    # step, then 2.16 ms, fresh buffers or not) -- how the runtime maps streams onto hardware queues, not the path.
+    rounds = []
     for rnd in range(2):
+        s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        for b in bufs:
+            b.run()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for i in range(steps):
             bufs[i % nbuf].run()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / steps
+        rounds.append((time.perf_counter() - t) / steps)
+    dt = min(rounds)
     if packed:
         assert int(bufs[0].h_totals[0]) <= cap and int(bufs[0].h_totals[1]) == 0 and int(bufs[0].h_status.sum()) == 0
         assert int(bufs[0].h_counts.to(torch.int64).sum()) == int(bufs[0].h_totals[0])
@@ -234,7 +238,7 @@ def from_host_rate(lib, ix, mode_id, host_reads, L, rows_per_read, steps=9, pack
     else:
         assert int(bufs[0].h_off[-1]) <= cap
         bytes_per_read = L + 8 + 16.0 * cap / N
-    return N * L / dt, dt * 1e3, bytes_per_read
+    return N * L / dt, dt * 1e3, bytes_per_read, [round(x * 1e3, 3) for x in rounds]
 
 
 def load_counters(key):
@@ -510,13 +514,13 @@ def main():
             saved_affinity = os.sched_getaffinity(0)
             node = bind_to_gpu_numa(device)
             host_reads = w["reads"].cpu().pin_memory()
-            v, ms, bpr = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=True)
-            v0, ms0, bpr0 = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=False)
-            line["value_from_host"] = {"value": v, "unit": "query-bases/s", "ms_per_step": ms, "link_bytes_per_read": round(bpr, 1),
+            v, ms, bpr, rr = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=True)
+            v0, ms0, bpr0, rr0 = from_host_rate(lib, ix, g._native.MODES[mode], host_reads, L, S, packed=False)
+            line["value_from_host"] = {"value": v, "unit": "query-bases/s", "ms_per_step": ms, "ms_per_step_rounds": rr, "link_bytes_per_read": round(bpr, 1),
                                        "what": "pinned host reads, 2-bit packed -> H2D -> genie_find_smems_packed -> D2H of count / status "
                                                "bytes + 8-byte rows, copy-in / kernels / copy-out pipelined on three streams (SURVEY 8d's wording of the metric; "
                                                "host-link bound; never `value`)",
-                                       "unpacked": {"value": v0, "ms_per_step": ms0, "link_bytes_per_read": round(bpr0, 1),
+                                       "unpacked": {"value": v0, "ms_per_step": ms0, "ms_per_step_rounds": rr0, "link_bytes_per_read": round(bpr0, 1),
                                                     "what": "the same through genie_find_smems_csr: a byte per base in, int64 offsets + 16-byte rows out"}}
             line["value_from_host"]["numa_node_bound"] = node
             os.sched_setaffinity(0, saved_affinity)

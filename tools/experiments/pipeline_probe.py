@@ -58,6 +58,12 @@ def run(variant, nbuf=3, steps=9):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / steps * 1e3
 
-for v in ("packed", "csr", "packed", "packed_rows_only", "csr"):
-    print(v, "%.3f ms" % run(v))
-print("packed nbuf 4 %.3f" % run("packed", 4, 12), " nbuf 6 %.3f" % run("packed", 6, 18))
+import subprocess
+print(subprocess.run("cat /sys/class/drm/card*/device/numa_node; nproc; cat /sys/devices/system/node/online", shell=True, capture_output=True, text=True).stdout)
+print("affinity", len(os.sched_getaffinity(0)))
+for v in ("packed", "packed", "packed", "csr", "packed", "packed"):
+    print(v, "%.3f ms" % run(v), flush=True)
+# fresh pinned blocks again (bigger cap so the cached blocks do not fit)
+cap = int(N * 14.1)
+for v in ("packed", "packed"):
+    print("bigger cap", v, "%.3f ms" % run(v), flush=True)
