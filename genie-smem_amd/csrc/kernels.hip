@@ -175,6 +175,16 @@ __device__ __forceinline__ int pick_probe(int lo, int hi, uint32_t xq32, uint32_
     return mid;
 }
 
+// The match-statistics kernel's hand-off rows leave with the non-temporal hint: 6 % off that kernel at 100 kb, 1 % at 1 Mb.
+// (The same hint on its input loads changed nothing; on the suffix-array rows of its deep path it cut the L2's misses by a
+// fifth and cost 12-18 % in time: tools/experiments/README.md.)
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+typedef nt_u4 nt_u4_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ void store_nt(void *dst, uint4 v)
+{
+    __builtin_nontemporal_store(nt_u4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u4 *>(dst));
+}
+
 __device__ __forceinline__ SaRec load_rec(const SaRec *sa, int row)
 {
     int4 v = *reinterpret_cast<const int4 *>(sa + row);                // one 16-byte load
