@@ -2,11 +2,11 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/sweep; mkdir -p $O
 for L in 100 150 250 500 1000 2000 4000 8000; do
   n=$((150000000 / L))
-  timeout -k 10 300 python $R/bench.py --read-len $L --reads $n --steps 10 --warmup 2 --no-cpu-baseline --no-from-host > $O/len_$L.json 2> $O/len_$L.err || exit 1
+  timeout -k 10 300 python $R/bench.py --read-len $L --reads $n --steps 10 --warmup 2 --no-cpu-baseline --no-from-host --no-other-configs > $O/len_$L.json 2> $O/len_$L.err || exit 1
 done
 for k in random; do
-  timeout -k 10 300 python $R/bench.py --read-kind $k --steps 10 --warmup 2 --no-cpu-baseline --no-from-host > $O/kind_$k.json 2> $O/kind_$k.err || exit 1
-  timeout -k 10 300 python $R/bench.py --read-kind $k --read-len 2000 --reads 75000 --steps 10 --warmup 2 --no-cpu-baseline --no-from-host > $O/kind_${k}_2000.json 2> $O/kind_${k}_2000.err || exit 1
+  timeout -k 10 300 python $R/bench.py --read-kind $k --steps 10 --warmup 2 --no-cpu-baseline --no-from-host --no-other-configs > $O/kind_$k.json 2> $O/kind_$k.err || exit 1
+  timeout -k 10 300 python $R/bench.py --read-kind $k --read-len 2000 --reads 75000 --steps 10 --warmup 2 --no-cpu-baseline --no-from-host --no-other-configs > $O/kind_${k}_2000.json 2> $O/kind_${k}_2000.err || exit 1
 done
 python3 - <<PY
 import json, glob, os
