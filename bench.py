@@ -1,29 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- query-bases/s of SMEM discovery on the BASELINE.json workloads.
 
-  python bench.py [--gpus N --steps K --warmup W] [--config 1|2|3|4] [--mode lut|rmi|bwa]
+  python bench.py [--gpus N --steps K --warmup W] [--config 1|2|3|4|5] [--mode lut|rmi|bwa]
 
 N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 one rank per GPU.  Rank 0 builds the index and broadcasts its image ONCE over RCCL (xGMI); after that ranks
 never communicate inside the timed region (reads are independent units).  Configs 1-3: weak scaling (every
 rank processes its own batch of the config's shape).  Config 4 (BASELINE configs[4]): strong scaling -- ONE
-80 M-read batch cut into contiguous shards with parallel.shard_bounds, per-rank outputs stay rank-local.
+80 M-read batch cut into contiguous shards with parallel.shard_bounds, per-rank outputs stay rank-local.  For N > 1 the
+line's `config` carries what the process group reports (backend, world_size) and broadcast_ms / broadcast_bytes.
 
 A "step" = one pass of the hot path over one batch: ONE genie_find_smems_csr call (match statistics, traversal,
-scan of the block sums, interval search writing the offsets and the CSR rows) with the reads already resident in HBM.  Rank 0 prints ONE
-JSON line (schema in the task contract) with `roofline` and `cpu_baseline`.
+scan of the block sums, interval search writing the offsets and the CSR rows) with the reads already resident in HBM
+(one code per base; generated on the device).  Rank 0 prints ONE JSON line (schema in the task contract) with `roofline`
+and `cpu_baseline`; the default run (config 1) also carries BASELINE configs 2 and 3 measured in the same process
+(`other_configs`) and `value_from_host` (pinned host buffers -> H2D -> call -> D2H through genie_find_smems_packed and,
+beside it, through the CSR entry point: the host link's rate, never `value`).
 
-What the roofline object says: the path moves few bytes and is bound by the rate of random
-L1->L2 requests and by vector-instruction issue, so
+What the roofline object says: the path moves few bytes and is bound by the L1 miss queue's
+concurrency x latency (and, on tables beyond an XCD's L2, by the L2's misses), so
   achieved / frac   = COMPULSORY HBM bytes of the dominant kernel (what it must read and write: the reads, its
                       hand-off rows) / its measured time, against the 8 TB/s HBM peak -- always <= 1;
   traffic           = its measured HBM bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes;
                       from profiles/pmc_counters.json, written by tools/profile_round.sh on the same workload);
   step              = the same two for the whole call (all kernels), and their ratio;
-  binding           = the counters that do bind (L1->L2 read requests vs the L2's rate, VALU issue share);
+  binding           = the counters that do bind (L1->L2 requests, their latency and number in flight, L2 misses, VALU issue);
   survey_8d         = the SURVEY 8(d) byte model (a 12-byte probe x ceil(log2 n) per position) for reference: the
-                      kernel does not do that work (one 32-byte table entry per position instead), so it is NOT
+                      kernel does not do that work (one 16-byte table entry per looked-up position instead), so it is NOT
                       reported as a fraction of anything.
 """
 import argparse
@@ -393,7 +397,7 @@ def roofline_of(w, offcfg=()):
             "survey_8d": {"alg_bytes_per_read": L + 16.0 * S + L * math.ceil(math.log2(cfg["n"] + 1)) * 12,
                           "equiv_GBps": (L + 16.0 * S + L * math.ceil(math.log2(cfg["n"] + 1)) * 12) * n_reads / (path_ms_avg * 1e-3) / 1e9,
                           "note": "SURVEY 8(d) prices a ceil(log2(n+1))-probe suffix-array search per position; the kernel "
-                                  "reads one 32-byte table entry per position instead, so this is an equivalent rate, not "
+                                  "reads one 16-byte table entry per looked-up position instead, so this is an equivalent rate, not "
                                   "a fraction of a roof"}}
     if ctr:
         ks = ctr["kernels"]
