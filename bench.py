@@ -93,8 +93,7 @@ def build_index(cfg, device):
     ref = synth.synth_ref(cfg["n"], cfg["ref_seed"])
     ix = g.GenieIndex.build(ref, K)
     coefs, icpts, _, _, _ = ix.train_rmi(EXPERTS)
-    full_bytes = int(ix.serialize().numel())
-    ix._host_blob = None
+    full_bytes = int(g._native.lib().genie_index_blob_bytes(ix._h))
     ix.to(device, seed_table=False)
     return ref, ix, {"coefs": coefs, "icpts": icpts, "full_image_bytes": full_bytes}
 
@@ -516,7 +515,8 @@ def main():
                        **par,
                        "smems_per_read": round(w["all_rows"] / w["all_reads"], 3), "launch": ix.launch_info(mode, L), "counters_key": key,
                        "index_build_s": round(w["t_build"], 3), "index_image_bytes": w["image_bytes"],
-                       "index_image_note": "image without the K-mer hash table (find_smems does not read it)"},
+                       "index_image_note": "image without the K-mer hash table (find_smems does not read it)",
+                       "index_full_image_bytes": (w["rl"] or {}).get("full_image_bytes")},
             "roofline": roof,
         }
         lib = g._native.lib()
