@@ -40,9 +40,16 @@ for seed in [int(x) for x in os.environ.get("SEEDS", "1").split()]:
             lens = None
             if rng.random() < 0.4:
                 lens = rng.integers(0, L + 1, N).astype(np.int32); lens[0] = L
-            ix = pkg.GenieIndex.build(ref, K)
+            fmt = "compact" if rng.random() < 0.7 else "wide"            # both forms of the match table
+            n_extra = 0
+            if rng.random() < 0.35 and n >= 3000 and alphabet == 4 and K >= 8:   # (the literal oracle's check_sequential is quadratic in a K-mer's
+                # occurrences: small K or a small alphabet on a big reference takes it minutes per case)
+                # a bigger reference now and then: the table outgrows
+                n_extra = int(rng.integers(200_000, 600_000))            # an XCD's L2, overflow blocks appear
+                ref = np.concatenate([ref, rng.integers(0, alphabet, n_extra).astype(np.uint8)])
+            ix = pkg.GenieIndex.build(ref, K, table_format=fmt)
             coefs, icpts, _, _, _ = ix.train_rmi([10])
-            ix = ix.to("cuda")
+            ix = ix.to("cuda", seed_table=bool(rng.random() < 0.5))
             o = oracle_mod.Oracle(ref, K)
             o.set_rmi([10], coefs, icpts)
             for algo in ("bwa", "lut", "rmi"):
@@ -55,7 +62,17 @@ for seed in [int(x) for x in os.environ.get("SEEDS", "1").split()]:
                     ok = (st[r] != 0) if counts[r] < 0 else (st[r] == 0 and rows[r].tolist() == out[r, :counts[r]].tolist())
                     if not ok:
                         bad += 1
-                        print("MISMATCH seed", seed, "n", n, "K", K, "L", L, algo, "read", r, "status", st[r], "oracle count", counts[r])
+                        print("MISMATCH seed", seed, "n", len(ref), fmt, "K", K, "L", L, algo, "read", r, "status", st[r], "oracle count", counts[r])
+                if L <= 255:                                             # the packed entry point gives the same rows
+                    import torch
+                    from genie_smem_amd import packing
+                    c8, s8, r8, esc = ix.find_smems_packed(algo, torch.as_tensor(packing.pack_reads(reads)).cuda(), L,
+                                                           lens=None if lens is None else torch.as_tensor(lens).cuda(), min_len=ml)
+                    off2, rows2 = packing.unpack_rows(c8.cpu().numpy(), r8.cpu().numpy(), esc.cpu().numpy())
+                    if not (np.array_equal(off2, offsets.cpu().numpy()) and np.array_equal(rows2, smems.cpu().numpy())
+                            and np.array_equal(s8.cpu().numpy().astype(np.int32), st)):
+                        bad += 1
+                        print("PACKED MISMATCH seed", seed, "n", len(ref), fmt, "K", K, "L", L, algo)
                 cases += 1
     print("seed", seed, "done:", cases, "cases so far,", bad, "mismatches", flush=True)
 print("TOTAL", cases, "cases,", bad, "mismatches")
