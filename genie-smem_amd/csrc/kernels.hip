@@ -701,7 +701,11 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     }
     if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
     g->block = wpb * kWave;
-    g->wps = !g->wide && table_bytes(ix) > kTableFitsL2 ? 4 : 8;
+    // waves per SIMD the kernel is built for: 4 (two blocks per CU) where the table exceeds an XCD's L2; else 6 for the compact
+    // table (74 registers, nothing spilled, three blocks per CU: 595-607 us against 609-611 us per 10^6 reads with the
+    // 64-register build and its 10 spilled registers -- the miss queue is full with three blocks' requests) and 8 for the
+    // 32-byte one
+    g->wps = !g->wide && table_bytes(ix) > kTableFitsL2 ? 4 : ((ix->dev.flags & kFlagCompactTable) ? 6 : 8);
     int bpc = std::min(lds_cap / g->lds, 4 * g->wps / wpb);                     // resident blocks per CU
     if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
     if (bpc < 1) bpc = 1;
@@ -787,9 +791,9 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
                            std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
     } else {
-        auto km = csr.packed ? (c16 ? (g.wps == 4 ? match_table_kernel<4, true, true> : match_table_kernel<8, true, true>)
+        auto km = csr.packed ? (c16 ? (g.wps == 4 ? match_table_kernel<4, true, true> : match_table_kernel<6, true, true>)
                                     : (g.wps == 4 ? match_table_kernel<4, false, true> : match_table_kernel<8, false, true>))
-                             : (c16 ? (g.wps == 4 ? match_table_kernel<4, true, false> : match_table_kernel<8, true, false>)
+                             : (c16 ? (g.wps == 4 ? match_table_kernel<4, true, false> : match_table_kernel<6, true, false>)
                                     : (g.wps == 4 ? match_table_kernel<4, false, false> : match_table_kernel<8, false, false>));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
@@ -908,7 +912,7 @@ int search_kernel_name(const genie_index *ix, int32_t mode, int32_t max_len, cha
     const bool big = table_bytes(ix) > kTableFitsL2, c16 = (ix->dev.flags & kFlagCompactTable) != 0;
     const char *name = max_len > 255 ? (c16 ? "match_table_long_kernel<true>" : "match_table_long_kernel<false>")
                                      : (big ? (c16 ? "match_table_kernel<4, true, false>" : "match_table_kernel<4, false, false>")
-                                            : (c16 ? "match_table_kernel<8, true, false>" : "match_table_kernel<8, false, false>"));
+                                            : (c16 ? "match_table_kernel<6, true, false>" : "match_table_kernel<8, false, false>"));
     if (!buf || cap < (int)strlen(name) + 1) return GENIE_E_CAPACITY;
     memcpy(buf, name, strlen(name) + 1);
     return GENIE_OK;

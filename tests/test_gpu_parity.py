@@ -650,7 +650,7 @@ def test_absent_base_is_flagged(pkg):
 def test_report_helpers(pkg):
     """genie_search_kernel_name / genie_launch_info: what bench.py and the profile summaries key on."""
     ix = _index(pkg, "syn10k_K8")
-    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<8, true, false>"      # <waves per SIMD, compact table, packed reads>
+    assert ix.search_kernel_name("lut", 150) == "match_table_kernel<6, true, false>"      # <waves per SIMD, compact table, packed reads>
     assert ix.search_kernel_name("bwa", 2000) == "match_table_long_kernel<true>"
     info = ix.launch_info("lut", 150)
     assert info["block"] == 512 and 0 < info["lds_bytes"] <= 160 * 1024 and info["grid"] > 0
@@ -772,7 +772,7 @@ def test_one_megabase_reference(pkg, oracle_mod):
     r = pkg.RMI_LUT([1000], 15, "REF_1M.fa", matcher=m)
     r.train_RMI()
     ix = r._index()
-    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<8, true, false>"      # 1 Mb: the compact table (4 MB of 16-byte entries)
+    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<6, true, false>"      # 1 Mb: the compact table (4 MB of 16-byte entries)
     o = oracle_mod.Oracle(ref, 15)
     coefs, icpts = r.rmi.coefficients()
     o.set_rmi([1000], coefs, icpts)
@@ -995,7 +995,7 @@ def test_table_forms_golden_and_oracle(pkg, oracle_mod, ds, fmt):
     ix = pkg.GenieIndex.build(ref, K, table_format=fmt)
     coefs, icpts, _, _, _ = ix.train_rmi([10, 100] if ds.startswith("medium") else [1000])
     ix = ix.to("cuda")
-    assert ix.search_kernel_name("lut", 150) == ("match_table_kernel<8, true, false>" if fmt == "compact" else "match_table_kernel<8, false, false>")
+    assert ix.search_kernel_name("lut", 150) == ("match_table_kernel<6, true, false>" if fmt == "compact" else "match_table_kernel<8, false, false>")
     for dsg, tag, algo in G.group_cases():
         if dsg != ds or algo == "rmi":
             continue
@@ -1087,7 +1087,7 @@ def test_packed_entry_point_equals_csr(pkg, oracle_mod):
     ref = np.concatenate([toks[i] for i in rng.choice(4, 400_000, p=[0.3, 0.2, 0.25, 0.25])])
     assert (ref == 0).sum() > 70_000 and not ((ref[:-1] == 0) & (ref[1:] != 1)).any()
     ix = pkg.GenieIndex.build(ref, 2).to("cuda")
-    assert ix.search_kernel_name("bwa", 40) == "match_table_kernel<8, true, false>"
+    assert ix.search_kernel_name("bwa", 40) == "match_table_kernel<6, true, false>"
     rd = rng.integers(0, 4, (300, 40)).astype(np.uint8)
     rd[:, 0::7] = 0
     rd[:, 1::7] = 2                                                   # 'AG': the A is an SMEM of one base

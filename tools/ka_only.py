@@ -24,6 +24,18 @@ out = torch.empty((N * max(40, L // 3), 4), dtype=torch.int32, device="cuda")
 wsb = int(lib.genie_find_smems_workspace_bytes(N, L)); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 P = lambda t: C.c_void_p(t.data_ptr())
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("PACKED"):
+    from genie_smem_amd import packing
+    pk = torch.as_tensor(packing.pack_reads(reads.cpu().numpy())).cuda()
+    c8 = torch.empty(N, dtype=torch.uint8, device="cuda"); s8 = torch.empty(N, dtype=torch.uint8, device="cuda")
+    r8 = torch.empty((out.shape[0], 8), dtype=torch.uint8, device="cuda"); tot = torch.zeros(2, dtype=torch.int64, device="cuda")
+    esc = torch.empty((1024, 2), dtype=torch.int64, device="cuda")
+    for _ in range(int(os.environ.get("ITERS", 8))):
+        rc = lib.genie_find_smems_packed(ix._h, g._native.MODES[mode], P(pk), None, N, pk.shape[1], L, 1, P(c8), P(s8), P(r8), r8.shape[0], P(tot), P(esc), 1024, P(ws), wsb, sp)
+        assert rc in (0, 1), rc
+    torch.cuda.synchronize()
+    print("ok packed")
+    sys.exit(0)
 for _ in range(int(os.environ.get("ITERS", 8))):
     rc = lib.genie_find_smems_csr(ix._h, g._native.MODES[mode], P(reads), None, N, L, L, 1, P(offsets), P(out), out.shape[0], P(status), P(ws), wsb, sp)
     assert rc in (0, 1), rc            # 1 = GENIE_W_SEARCH_ONLY

@@ -9,6 +9,6 @@ echo "$RUNS" | while IFS= read -r envs; do
   python3 - <<PY
 import csv
 rows=[r for r in csv.DictReader(open("$O/kt_kernel_stats.csv")) if "genie" in r["Name"]]
-print("$envs:", "; ".join("%s %.1f us"%(r["Name"].replace("(anonymous namespace)::","").replace("void ","").split("(")[0].split("::")[-1][:28], float(r["AverageNs"])/1e3) for r in rows[:3]))
+print("$envs:", "; ".join("%s %.1f us"%(r["Name"].replace("(anonymous namespace)::","").replace("void ","").split("(")[0].split("::")[-1][:28], float(r["AverageNs"])/1e3) for r in rows[:4]))
 PY
 done
