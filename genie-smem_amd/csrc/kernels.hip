@@ -704,7 +704,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     // waves per SIMD the kernel is built for: 4 (two blocks per CU) where the table exceeds an XCD's L2; else 6 for the compact
     // table (74 registers, nothing spilled, three blocks per CU: 595-607 us against 609-611 us per 10^6 reads with the
     // 64-register build and its 10 spilled registers -- the miss queue is full with three blocks' requests) and 8 for the
-    // 32-byte one
+    // 32-byte one (on the 16 MB table of a 2.5 Mb reference the six-wave build was no faster than the four-wave one: 6.22 vs 6.10 ms)
     g->wps = !g->wide && table_bytes(ix) > kTableFitsL2 ? 4 : ((ix->dev.flags & kFlagCompactTable) ? 6 : 8);
     int bpc = std::min(lds_cap / g->lds, 4 * g->wps / wpb);                     // resident blocks per CU
     if (ix->opt_search_blocks_per_cu > 0) bpc = std::min(bpc, ix->opt_search_blocks_per_cu);
