@@ -1098,6 +1098,28 @@ def test_packed_entry_point_equals_csr(pkg, oracle_mod):
     assert (rows[:, 3] - rows[:, 2] >= 65535).sum() > 300
     for i in range(300):
         assert rows[off[i]:off[i + 1]].tolist() == want[i, :counts[i]].tolist(), i
+    # argument checks of the entry point itself
+    import ctypes as C
+    lib = pkg._native.lib()
+    pk = torch.as_tensor(packing.pack_reads(rd)).cuda()
+    c8 = torch.empty(300, dtype=torch.uint8, device="cuda")
+    r8 = torch.empty((4096, 8), dtype=torch.uint8, device="cuda")
+    tot = torch.zeros(2, dtype=torch.int64, device="cuda")
+    wsb = int(lib.genie_find_smems_workspace_bytes(300, 300))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())                                                  # noqa: E731
+
+    def call(stride=pk.shape[1], L=40, reads=pk, rows=r8, totals=tot):
+        return lib.genie_find_smems_packed(ix._h, 0, P(reads), None, 300, stride, L, 1, P(c8), P(c8), P(rows), 4096, P(totals), None, 0,
+                                           P(ws), wsb, None)
+    assert call(L=256) == -6                                           # start / end are bytes
+    assert call(stride=pk.shape[1] + 2) == -1 and call(stride=8) == -1          # a multiple of 4, at least 4 * ceil(L / 16)
+    assert lib.genie_find_smems_packed(ix._h, 0, C.c_void_p(pk.data_ptr() + 1), None, 300, pk.shape[1], 40, 1, P(c8), P(c8), P(r8), 4096,
+                                       P(tot), None, 0, P(ws), wsb, None) == -1            # misaligned reads
+    assert lib.genie_find_smems_packed(ix._h, 7, P(pk), None, 300, pk.shape[1], 40, 1, P(c8), P(c8), P(r8), 4096, P(tot), None, 0,
+                                       P(ws), wsb, None) == -1                              # no such mode
+    assert call() == 0 and int(tot[1].item()) > 300                    # no escape list given: the count still says how many there are
+    torch.cuda.synchronize()
     # a bad base is caught while packing on the host, as the reference raises KeyError
     bad = rd[:3].copy()
     bad[1, 5] = 7
