@@ -1207,3 +1207,37 @@ def test_two_and_a_half_megabase_reference(pkg, oracle_mod):
     got = ix.sa_interval(pats, lens).cpu().numpy()
     for i in range(1500):
         assert tuple(got[i]) == o.back_prop(pats[i, :lens[i]]), i
+
+
+def test_seventeen_megabase_reference_takes_the_wide_table(pkg, oracle_mod):
+    """Past 2^24 bases a suffix-array row no longer fits the compact entries' 24 bits: the index falls back to the
+    32-byte form by itself.  17 000 000 synthetic bases (P2 = 12: a 537 MB match table, a 1 GB image), K = 15, natively
+    trained RMI: from-ref and random reads in the three modes and exact-match patterns against the CPU oracle."""
+    from genie_smem_amd import synth as B
+    n = 17_000_000
+    ref = B.synth_ref(n, n)
+    ix = pkg.GenieIndex.build(ref, 15)
+    coefs, icpts, _, _, _ = ix.train_rmi([1000])
+    ix = ix.to("cuda", seed_table=False)
+    assert ix.search_kernel_name("rmi", 150) == "match_table_kernel<4, false, false>"
+    o = oracle_mod.Oracle(ref, 15)
+    o.set_rmi([1000], coefs, icpts)
+    for kind, rd in (("fromref", B.reads_from_ref(ref, 2000, 150, 1701)), ("random", B.reads_random(500, 150, 1702))):
+        for algo in ("bwa", "lut", "rmi"):
+            offsets, smems, st = ix.find_smems(algo, rd)
+            assert int(st.abs().sum().item()) == 0
+            rows = _rows_per_read(offsets, smems)
+            counts, want = o.find_smems_batch(algo, rd, nthreads=16)
+            for i in range(len(rd)):
+                assert rows[i].tolist() == want[i, :counts[i]].tolist(), (kind, algo, i)
+    rng = np.random.default_rng(17)
+    pats = np.zeros((1000, 60), np.uint8)
+    lens = rng.integers(1, 61, 1000).astype(np.int32)
+    for i in range(1000):
+        p0 = int(rng.integers(0, n - 60))
+        pats[i, :lens[i]] = ref[p0:p0 + lens[i]]
+        if i % 3 == 0:
+            pats[i, lens[i] - 1] = (pats[i, lens[i] - 1] + 1) % 4
+    got = ix.sa_interval(pats, lens).cpu().numpy()
+    for i in range(1000):
+        assert tuple(got[i]) == o.back_prop(pats[i, :lens[i]]), i
