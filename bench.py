@@ -14,8 +14,9 @@ line's `config` carries what the process group reports (backend, world_size) and
 A "step" = one pass of the hot path over one batch: ONE genie_find_smems_csr call (match statistics, traversal,
 scan of the block sums, interval search writing the offsets and the CSR rows) with the reads already resident in HBM
 (one code per base; generated on the device).  Rank 0 prints ONE JSON line (schema in the task contract) with `roofline`
-and `cpu_baseline`; the default run (config 1) also carries BASELINE configs 2 and 3 measured in the same process
-(`other_configs`) and `value_from_host` (pinned host buffers -> H2D -> call -> D2H through genie_find_smems_packed and,
+and `cpu_baseline`; the default run (config 1) also carries the other BASELINE configs measured in the same process
+(`other_configs`: configs 2, 3 and 4 on one GPU; on N > 1 GPUs config 3, weak, and config 4, the 8 x 10^7-read batch cut
+into N shards, strong -- each record with its own n_gpus / scaling / broadcast_ms) and `value_from_host` (pinned host buffers -> H2D -> call -> D2H through genie_find_smems_packed and,
 beside it, through the CSR entry point: the host link's rate, never `value`).
 
 What the roofline object says: the path moves few bytes and is bound by the L1 miss queue's
@@ -447,7 +448,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the config 2 / config 3 records appended to the default line")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the records of the other BASELINE configs appended to the default line")
     ap.add_argument("--search-all", action="store_true", help="GENIE_OPT_SEARCH_ALL: look up every position, no sampling (A/B runs)")
     args = ap.parse_args()
 
@@ -575,24 +576,33 @@ def main():
             for r in range(nchk):
                 assert (s2[o2[r]:o2[r + 1]] == rows_s[r, :cnt_s[r]]).all(), f"GPU/oracle rows differ at sample read {r}"
             line["cpu_baseline"]["parity_check"] = f"{nchk} sample reads: GPU (start, end, lo, hi) rows == oracle rows"
-        # ---- the default (driver-run) line also carries BASELINE configs[2] and [3], measured in the same process with
-        # fewer steps: config 1 stays the headline `value`
-        if world == 1 and args.config == 1 and not offcfg and not args.reads and not args.no_other_configs:
-            del w
-            torch.cuda.empty_cache()
-            line["other_configs"] = []
-            for cid, st in ((2, 5), (3, 3)):
-                w2 = run_workload(args, cid, CONFIGS[cid]["mode"], st, 1, world, rank, device)
+    # ---- the default (driver-run) line also carries the other BASELINE configs, measured in the same process with fewer
+    # steps (config 1 stays the headline `value`): on one GPU configs[2], [3] and [4] (the 8 x 10^7-read batch whole); on
+    # N > 1 GPUs configs[3] (weak: 10^7 reads per rank) and configs[4] (strong: the one batch cut into N contiguous shards)
+    if args.config == 1 and not offcfg and not args.reads and not args.no_other_configs:
+        del w, ix
+        torch.cuda.empty_cache()
+        others = []
+        for cid, st in (((2, 5), (3, 3), (4, 2)) if world == 1 else ((3, 3), (4, 2))):
+            w2 = run_workload(args, cid, CONFIGS[cid]["mode"], st, 1, world, rank, device)
+            if rank == 0:
                 r2, key2, S2, ms2 = roofline_of(w2)
-                line["other_configs"].append({
-                    "config": CONFIGS[cid]["name"], "baseline_configs_index": cid, "mode": w2["mode"],
-                    "value": w2["all_reads"] * w2["L"] * st / w2["dt"], "unit": "query-bases/s", "steps": st, "warmup": 1,
-                    "ms_per_step": ms2, "reads_per_step": w2["n_reads"], "smems_per_read": round(S2, 3),
-                    "kernel": r2["kernel"], "kernel_ms_avg": r2["kernel_ms_avg"],
-                    "roofline": {k: r2.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw")},
-                    "counters_key": key2})
-                del w2
-                torch.cuda.empty_cache()
+                rec = {"config": CONFIGS[cid]["name"], "baseline_configs_index": cid, "mode": w2["mode"],
+                       "value": w2["all_reads"] * w2["L"] * st / w2["dt"], "unit": "query-bases/s", "n_gpus": world,
+                       "scaling": w2["cfg"]["scaling"], "steps": st, "warmup": 1,
+                       "ms_per_step": ms2, "reads_per_step_all_gpus": w2["all_reads"], "reads_per_gpu_per_step": w2["n_reads"],
+                       "smems_per_read": round(w2["all_rows"] / w2["all_reads"], 3),
+                       "kernel": r2["kernel"], "kernel_ms_avg": r2["kernel_ms_avg"],
+                       "roofline": {k: r2.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw")},
+                       "counters_key": key2}
+                if world > 1:
+                    rec.update({"broadcast_ms": round(w2["broadcast_ms"], 3), "broadcast_bytes": w2["image_bytes"]})
+                others.append(rec)
+            del w2
+            torch.cuda.empty_cache()
+        if rank == 0:
+            line["other_configs"] = others
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
