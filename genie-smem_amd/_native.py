@@ -28,6 +28,7 @@ OPT_GROUP_POSITIONS = 4
 OPT_SEARCH_ONLY = 5
 OPT_SEARCH_BLOCKS_PER_CU = 6
 OPT_SEARCH_STAGES_OFF = 7
+OPT_SCHEDULING = 8
 READ_OK, READ_BAD_BASE, READ_TOO_SHORT, READ_ABSENT_BASE, READ_OVERFLOW = 0, 1, 2, 3, 4
 
 # every symbol include/genie_smem.h declares (tests check the library exports all of them)

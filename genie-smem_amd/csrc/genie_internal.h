@@ -261,6 +261,7 @@ struct genie_index {
     int32_t opt_search_all = 0;      // GENIE_OPT_SEARCH_ALL
     int32_t opt_group_positions = 0; // GENIE_OPT_GROUP_POSITIONS (0 = default)
     int32_t opt_search_only = 0;     // GENIE_OPT_SEARCH_ONLY
+    int32_t opt_scheduling = 0;      // GENIE_OPT_SCHEDULING bits (A/B timing; results unchanged)
     int32_t opt_debug = 0;           // experiments: stages of the search kernel switched off (results invalid)
     int32_t opt_search_blocks_per_cu = 0;   // GENIE_OPT_SEARCH_BLOCKS_PER_CU (0 = as many as fit)
     void *ev_search_begin = nullptr; // optional hipEvent_t pair bracketing the search kernel

@@ -28,6 +28,17 @@ constexpr int kWave = 64;
 
 // ------------------------------------------------------------------ small wave helpers
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Issue priority of the calling wave: level `i` mod 4 (s_setprio takes an immediate).  A CU serves its oldest waves first; waves
+// of a persistent kernel that change their level as they go share the CU evenly instead (match_table_kernel.inc).
+__device__ __forceinline__ void set_wave_priority(int i)
+{
+    switch (i & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 
 // LDS traffic between lanes of ONE wave: the LDS executes a wave's instructions in order, so
 // only the compiler has to be stopped from reordering.
@@ -696,7 +707,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
         const int ml = std::max(max_len, 1);
         const int grp = ix->opt_group_positions > 0 ? ix->opt_group_positions / ml : kMtTarget / ml;
         g->grp = std::max(1, std::min(std::min(kMtMaxG, kWave / mt_pack_dwords(ml) * 4), grp));
-        g->lds = wpb * mt_wave_bytes(g->grp, ml, g->qp_recs, g->fwd_stride);
+        g->lds = wpb * mt_wave_bytes(g->grp, ml, g->qp_recs, g->fwd_stride) + 16;     // + the block's group counter
         per_block = (long long)wpb * g->grp;
     }
     if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
@@ -798,7 +809,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, g.qp_stride, st,
-                           g.grp, std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_debug << 8);
+                           g.grp, std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_debug << 8 | ix->opt_scheduling << 16, ix->num_cus > 0 ? ix->num_cus : 256);
     }
     HIP_TRY(hipGetLastError());
     if (ix->ev_search_end) HIP_TRY(hipEventRecord((hipEvent_t)ix->ev_search_end, s));
@@ -840,6 +851,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
     RowEscapes esc{nullptr, nullptr, 0};
+    const int sched_c = (ix->opt_scheduling >> 2) | cus << 8;        // bit 0: no priority rotation; bits 8..: CUs (blocks per round)
     if (csr.packed) {
         esc.count = reinterpret_cast<unsigned long long *>(csr.offsets) + 1;
         esc.list = reinterpret_cast<long long *>(csr.escapes);
@@ -848,7 +860,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         auto kp = c16 ? interval_kernel<true, false, true, true> : interval_kernel<true, false, false, true>;
         hipLaunchKernelGGL(kp, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
                            ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(csr.rows), 0,
-                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc);
+                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc, sched_c);
         HIP_TRY(hipGetLastError());
         return GENIE_OK;
     }
@@ -857,10 +869,10 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     if (csr.offsets)
         hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
                            ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(csr.rows), 0,
-                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc);
+                           reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc, sched_c);
     else
         hipLaunchKernelGGL(kc, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
-                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(d_slots), cap, nullptr, 0ll, nullptr, nullptr, 0, esc);
+                           ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(d_slots), cap, nullptr, 0ll, nullptr, nullptr, 0, esc, sched_c);
     HIP_TRY(hipGetLastError());
     return GENIE_OK;
 }

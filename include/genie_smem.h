@@ -268,9 +268,12 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  *   find_smems entry points return GENIE_W_SEARCH_ONLY instead of GENIE_OK; for timing that kernel alone.
  * GENIE_OPT_SEARCH_STAGES_OFF (default 0; honoured only while GENIE_OPT_SEARCH_ONLY is set, so never on a run that
  *   produces output): bit mask of stages of that kernel to skip -- 1 slow list, 2 round 2, 4 rounds 1+2, 8 packed-read
- *   records, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh). */
+ *   records, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh).
+ * GENIE_OPT_SCHEDULING (default 0; A/B timing, results unchanged): bit mask -- 1: the match-statistics kernel gives every
+ *   wave a fixed share of the read groups instead of handing them out per block; 2: its waves keep one issue priority
+ *   instead of rotating it; 4: the same for the interval kernel. */
 enum { GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_GROUP_POSITIONS = 4, GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6,
-       GENIE_OPT_SEARCH_STAGES_OFF = 7 };
+       GENIE_OPT_SEARCH_STAGES_OFF = 7, GENIE_OPT_SCHEDULING = 8 };
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);
 
 /* Profiling hook: two hipEvent_t (as void*, created by the caller with timing enabled) that the next
