@@ -699,7 +699,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     long long per_block;
     if (g->wide) {
         g->grp = 1;
-        g->lds = wpb * mt_long_wave_bytes(max_len, g->qp_recs);
+        g->lds = wpb * mt_long_wave_bytes(max_len, g->qp_recs) + 16;                  // + the block's counter of reads handed out
         per_block = wpb;
     } else {
         // `grp` reads per wave iteration: about kMtTarget positions (one round-1 pass of 3 x 64 quads), and no
@@ -800,7 +800,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(km), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
         hipLaunchKernelGGL(km, dim3(g.grid), dim3(g.block), g.lds, s, ix->dev, (int)MODE, d_reads, d_lens, (long long)N, stride,
                            fixed_len, reinterpret_cast<uint8_t *>(ws.fwd), g.fwd_stride, ws.qp, g.qp_recs, st,
-                           std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all);
+                           std::max(g.max_len, 1), mtab_bytes, ix->opt_search_all | ix->opt_scheduling << 16, ix->num_cus > 0 ? ix->num_cus : 256);
     } else {
         auto km = csr.packed ? (c16 ? (g.wps == 4 ? match_table_kernel<4, true, true> : match_table_kernel<6, true, true>)
                                     : (g.wps == 4 ? match_table_kernel<4, false, true> : match_table_kernel<8, false, true>))

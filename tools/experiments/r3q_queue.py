@@ -8,10 +8,11 @@ from genie_smem_amd import synth
 lib = g._native.lib()
 P = lambda t: C.c_void_p(t.data_ptr())
 VARS = [int(x) for x in os.environ.get("VARS", "0 4 2 6 3 7").split()]
-for n, N, kind in ((100_000, 1_000_000, "fromref"), (1_000_000, 4_000_000, "fromref"), (100_000, 1_000_000, "random")):
+CASES = ((100_000, 1_000_000, "fromref", 150), (1_000_000, 4_000_000, "fromref", 150), (100_000, 1_000_000, "random", 150),
+         (100_000, 300_000, "fromref", 500), (100_000, 75_000, "fromref", 2000), (100_000, 18_750, "fromref", 8000))
+for n, N, kind, L in CASES[int(os.environ.get("FIRST_CASE", "0")):]:
     ref = synth.synth_ref(n, n)
     ix = g.GenieIndex.build(ref, 15); ix.train_rmi([1000]); ix = ix.to("cuda")
-    L = 150
     if kind == "random":
         reads = torch.as_tensor(np.random.default_rng(7).integers(0, 4, (N, L)).astype(np.uint8)).cuda()
     else:
@@ -39,4 +40,4 @@ for n, N, kind in ((100_000, 1_000_000, "fromref"), (1_000_000, 4_000_000, "from
             if rep == 0:                                         # the same rows whatever the schedule
                 tot = int(offsets[-1].item()); chk = (int(out[:tot].to(torch.int64).sum().item()), tot)
                 assert ref_rows in (None, chk), (v, chk, ref_rows); ref_rows = chk
-    print(n, N, kind, "  ".join("[%d] K_A %.4f call %.4f" % (v, np.median(ka[v]), np.median(call[v])) for v in VARS), flush=True)
+    print(n, N, kind, L, "  ".join("[%d] K_A %.4f call %.4f" % (v, np.median(ka[v]), np.median(call[v])) for v in VARS), flush=True)
