@@ -13,6 +13,7 @@ CASES = ((100_000, 1_000_000, "fromref", 150), (1_000_000, 4_000_000, "fromref",
 for n, N, kind, L in CASES[int(os.environ.get("FIRST_CASE", "0")):]:
     ref = synth.synth_ref(n, n)
     ix = g.GenieIndex.build(ref, 15); ix.train_rmi([1000]); ix = ix.to("cuda")
+    if os.environ.get("BPC"): ix.set_option(g._native.OPT_SEARCH_BLOCKS_PER_CU, int(os.environ["BPC"]))
     if kind == "random":
         reads = torch.as_tensor(np.random.default_rng(7).integers(0, 4, (N, L)).astype(np.uint8)).cuda()
     else:
