@@ -36,7 +36,7 @@ SYMBOLS = [
     "genie_abi_version", "genie_index_create", "genie_index_create_from_sa", "genie_index_create_ex", "genie_index_set_rmi",
     "genie_index_info", "genie_index_suffix_array", "genie_index_lut_arrays", "genie_index_blob_bytes",
     "genie_index_serialize", "genie_index_image_bytes", "genie_index_serialize_image", "genie_index_open", "genie_index_validate", "genie_index_to_device", "genie_index_destroy",
-    "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_csr", "genie_find_smems_packed", "genie_find_smems_workspace_bytes", "genie_find_smems_workspace_rows",
+    "genie_sa_interval", "genie_seed_lookup", "genie_find_smems", "genie_find_smems_csr", "genie_find_smems_packed", "genie_find_smems_packed6", "genie_find_smems_workspace_bytes", "genie_find_smems_workspace_rows",
     "genie_compact_tmp_bytes",
     "genie_compact_smems", "genie_locate_tmp_bytes", "genie_locate", "genie_index_train_rmi", "genie_index_rmi_models", "genie_launch_info", "genie_search_kernel_name", "genie_index_set_option", "genie_index_set_stage_events", "genie_strerror", "genie_last_hip_error",
 ]
@@ -105,6 +105,7 @@ def lib():
         "genie_find_smems": (C.c_int, [vp, i32, vp, vp, i64, i32, i32, i32, vp, vp, i32, vp, vp, i64, vp]),
         "genie_find_smems_csr": (C.c_int, [vp, i32, vp, vp, i64, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp]),
         "genie_find_smems_packed": (C.c_int, [vp, i32, vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp, vp, i64, vp, i64, vp]),
+        "genie_find_smems_packed6": (C.c_int, [vp, i32, vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp, vp, i64, vp, i64, vp]),
         "genie_find_smems_workspace_bytes": (i64, [i64, i32]),
         "genie_find_smems_workspace_rows": (C.c_int, [i32, i32p]),
         "genie_compact_tmp_bytes": (i64, [i64]),

@@ -311,26 +311,45 @@ int genie_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_r
                                  d_status, d_workspace, workspace_bytes, stream);
 }
 
-int genie_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *d_reads2bit, const int32_t *d_lens, int64_t N,
-                            int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
-                            void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
-                            void *d_workspace, int64_t workspace_bytes, void *stream)
+static int find_smems_packed_any(const genie_index *ix, int32_t mode, const uint8_t *d_reads2bit, const int32_t *d_lens, int64_t N,
+                                 int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
+                                 void *d_rows, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
+                                 void *d_workspace, int64_t workspace_bytes, void *stream, int row_bytes)
 {
     int rc = ready(ix);
     if (rc) return rc;
     if (N < 0 || stride_bytes < 0 || fixed_len < 0 || out_cap_rows < 0 || cap_escapes < 0 || !d_totals ||
-        (N > 0 && (!d_reads2bit || !d_rows8 || !d_counts8 || !d_status8)) || (cap_escapes > 0 && !d_escapes))
+        (N > 0 && (!d_reads2bit || !d_rows || !d_counts8 || !d_status8)) || (cap_escapes > 0 && !d_escapes))
         return GENIE_E_INVALID;
     if (mode < GENIE_MODE_BWA || mode > GENIE_MODE_RMI) return GENIE_E_INVALID;
-    if (fixed_len > 255) return GENIE_E_TOO_LONG;                       // start / end are bytes in the 8-byte rows
+    if (fixed_len > 255) return GENIE_E_TOO_LONG;                       // start / end are bytes in the compact rows
+    if (row_bytes == 6 && (int64_t)ix->dev.n + 1 >= (1ll << 24)) return GENIE_E_TOO_LONG;       // lo is 24 bits in the 6-byte rows
     if ((stride_bytes & 3) != 0 || stride_bytes < 4 * ((fixed_len + 15) / 16)) return GENIE_E_INVALID;
-    if ((reinterpret_cast<uintptr_t>(d_reads2bit) & 3) != 0 || (reinterpret_cast<uintptr_t>(d_rows8) & 7) != 0 ||
+    if ((reinterpret_cast<uintptr_t>(d_reads2bit) & 3) != 0 || (reinterpret_cast<uintptr_t>(d_rows) & (row_bytes == 6 ? 1 : 7)) != 0 ||
         (reinterpret_cast<uintptr_t>(d_totals) & 7) != 0)
         return GENIE_E_INVALID;
     if (mode != GENIE_MODE_BWA && ix->dev.K < 1) return GENIE_E_NO_LUT;
     if (mode == GENIE_MODE_RMI && ix->dev.nlev < 1) return GENIE_E_NO_MODEL;
     return launch_find_smems_packed(ix, mode, d_reads2bit, d_lens, N, stride_bytes, fixed_len, min_len, d_counts8, d_status8,
-                                    d_rows8, out_cap_rows, d_totals, d_escapes, cap_escapes, d_workspace, workspace_bytes, stream);
+                                    d_rows, out_cap_rows, d_totals, d_escapes, cap_escapes, d_workspace, workspace_bytes, stream, row_bytes);
+}
+
+int genie_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *d_reads2bit, const int32_t *d_lens, int64_t N,
+                            int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
+                            void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
+                            void *d_workspace, int64_t workspace_bytes, void *stream)
+{
+    return find_smems_packed_any(ix, mode, d_reads2bit, d_lens, N, stride_bytes, fixed_len, min_len, d_counts8, d_status8, d_rows8,
+                                 out_cap_rows, d_totals, d_escapes, cap_escapes, d_workspace, workspace_bytes, stream, 8);
+}
+
+int genie_find_smems_packed6(const genie_index *ix, int32_t mode, const uint8_t *d_reads2bit, const int32_t *d_lens, int64_t N,
+                             int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
+                             void *d_rows6, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
+                             void *d_workspace, int64_t workspace_bytes, void *stream)
+{
+    return find_smems_packed_any(ix, mode, d_reads2bit, d_lens, N, stride_bytes, fixed_len, min_len, d_counts8, d_status8, d_rows6,
+                                 out_cap_rows, d_totals, d_escapes, cap_escapes, d_workspace, workspace_bytes, stream, 6);
 }
 
 int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len)

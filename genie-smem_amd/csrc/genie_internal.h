@@ -285,7 +285,7 @@ int launch_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_
 int launch_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *d_reads2, const int32_t *d_lens, int64_t N,
                              int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
                              void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
-                             void *d_ws, int64_t ws_bytes, void *stream);
+                             void *d_ws, int64_t ws_bytes, void *stream, int row_bytes = 8);
 int launch_compact(const int32_t *d_counts, const int32_t *d_slots, int64_t N, int32_t cap, int64_t *d_offsets,
                    int32_t *d_out, int64_t out_cap_rows, void *d_tmp, void *stream);
 int64_t compact_tmp_bytes(int64_t N);

@@ -780,6 +780,7 @@ struct CsrOut {
     // genie_find_smems_packed: 2-bit packed reads in; 8-byte rows, a count byte and a status byte per read out.
     // `offsets` then points at the totals (word 0 = rows, word 1 = escapes); `rows` at the 8-byte rows.
     bool packed = false;
+    int row_bytes = 8;               // 8 or 6 (genie_find_smems_packed6)
     uint8_t *counts8 = nullptr, *status8 = nullptr;
     int64_t *escapes = nullptr;
     int64_t cap_escapes = 0;
@@ -857,7 +858,8 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
         esc.list = reinterpret_cast<long long *>(csr.escapes);
         esc.cap = csr.cap_escapes;
         HIP_TRY(hipMemsetAsync(csr.offsets, 0, 16, s));
-        auto kp = c16 ? interval_kernel<true, false, true, true> : interval_kernel<true, false, false, true>;
+        auto kp = csr.row_bytes == 6 ? (c16 ? interval_kernel<true, false, true, 2> : interval_kernel<true, false, false, 2>)
+                                     : (c16 ? interval_kernel<true, false, true, 1> : interval_kernel<true, false, false, 1>);
         hipLaunchKernelGGL(kp, dim3((unsigned)grid_c), dim3(kIvWaves * kWave), 0, s, ix->dev, (long long)N,
                            ws.kj, g.kj_row, head, head_stride, ws.qp, g.qp_stride, reinterpret_cast<void *>(csr.rows), 0,
                            reinterpret_cast<long long *>(csr.offsets), (long long)csr.cap_rows, bsums, cnt, block_shift, esc, sched_c);
@@ -993,7 +995,7 @@ int launch_find_smems_csr(const genie_index *ix, int32_t mode, const uint8_t *d_
 int launch_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *d_reads2, const int32_t *d_lens, int64_t N,
                              int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
                              void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
-                             void *d_ws, int64_t ws_bytes, void *stream)
+                             void *d_ws, int64_t ws_bytes, void *stream, int row_bytes)
 {
     if (N == 0) {
         HIP_TRY(hipMemsetAsync(d_totals, 0, 16, (hipStream_t)stream));
@@ -1004,6 +1006,7 @@ int launch_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t 
     csr.rows = reinterpret_cast<int32_t *>(d_rows8);
     csr.cap_rows = out_cap_rows;
     csr.packed = true;
+    csr.row_bytes = row_bytes;
     csr.counts8 = d_counts8;
     csr.status8 = d_status8;
     csr.escapes = d_escapes;

@@ -341,10 +341,13 @@ class GenieIndex:
                 return offsets, rows[:total], status
             cap_rows = total                      # capacity guess too small: rerun with the exact size
 
-    def find_smems_packed(self, mode, packed, max_len, lens=None, min_len=1, rows_hint=None):
-        """genie_find_smems_packed: 2-bit packed reads (packing.pack_reads; uint8 [N, stride] on the device) ->
-        (counts8 uint8[N], status8 uint8[N], rows8 uint8[S, 8], escapes int64[E, 2]); packing.unpack_rows turns them
-        into the offsets / int32 rows of find_smems.  Reads of at most 255 bases."""
+    def find_smems_packed(self, mode, packed, max_len, lens=None, min_len=1, rows_hint=None, row_bytes=8):
+        """genie_find_smems_packed (or, `row_bytes` = 6, genie_find_smems_packed6): 2-bit packed reads (packing.pack_reads;
+        uint8 [N, stride] on the device) -> (counts8 uint8[N], status8 uint8[N], rows uint8[S, row_bytes], escapes int64[E, 2]);
+        packing.unpack_rows turns them into the offsets / int32 rows of find_smems.  Reads of at most 255 bases."""
+        if row_bytes not in (6, 8):
+            raise ValueError("row_bytes is 6 or 8")
+        entry = N.lib().genie_find_smems_packed if row_bytes == 8 else N.lib().genie_find_smems_packed6
         self._need_device()
         packed = self._as_dev(packed, torch.uint8)
         if packed.dim() != 2:
@@ -356,16 +359,16 @@ class GenieIndex:
         status8 = torch.zeros(n_reads, dtype=torch.uint8, device=self.device)
         totals = torch.zeros(2, dtype=torch.int64, device=self.device)
         if n_reads == 0:
-            return counts8, status8, torch.zeros((0, 8), dtype=torch.uint8, device=self.device), torch.zeros((0, 2), dtype=torch.int64, device=self.device)
+            return counts8, status8, torch.zeros((0, row_bytes), dtype=torch.uint8, device=self.device), torch.zeros((0, 2), dtype=torch.int64, device=self.device)
         ws_bytes = int(N.lib().genie_find_smems_workspace_bytes(n_reads, int(max_len)))
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=self.device)
         cap_rows = int(rows_hint) if rows_hint else n_reads * max(8, int(max_len) // 6)
         cap_esc = 1024
         while True:
-            rows8 = torch.empty((max(cap_rows, 1), 8), dtype=torch.uint8, device=self.device)
+            rows8 = torch.empty((max(cap_rows, 1), row_bytes), dtype=torch.uint8, device=self.device)
             esc = torch.empty((max(cap_esc, 1), 2), dtype=torch.int64, device=self.device)
             with torch.cuda.device(self.device):
-                N.check(N.lib().genie_find_smems_packed(self._h, N.MODES[mode], _ptr(packed), _ptr(lens), n_reads, stride,
+                N.check(entry(self._h, N.MODES[mode], _ptr(packed), _ptr(lens), n_reads, stride,
                                                         int(max_len), int(min_len), _ptr(counts8), _ptr(status8), _ptr(rows8),
                                                         rows8.shape[0], _ptr(totals), _ptr(esc), esc.shape[0], _ptr(ws), ws_bytes,
                                                         _stream(self.device)), "genie_find_smems_packed")
@@ -380,8 +383,9 @@ class GenieIndex:
         from . import packing
         codes = np.ascontiguousarray(codes, np.uint8)
         packed = torch.as_tensor(packing.pack_reads(codes))
-        c8, s8, r8, esc = self.find_smems_packed(mode, packed, codes.shape[1], lens=lens, min_len=min_len)
-        offsets, rows = packing.unpack_rows(c8.cpu().numpy(), r8.cpu().numpy(), esc.cpu().numpy())
+        rb = 6 if self.n + 1 < (1 << 24) else 8                     # the 6-byte rows hold lo in 24 bits
+        c8, s8, r8, esc = self.find_smems_packed(mode, packed, codes.shape[1], lens=lens, min_len=min_len, row_bytes=rb)
+        offsets, rows = packing.unpack_rows(c8.cpu().numpy(), r8.cpu().numpy(), esc.cpu().numpy(), row_bytes=rb)
         return offsets, rows, s8.cpu().numpy().astype(np.int32)
 
     def set_option(self, option, value):

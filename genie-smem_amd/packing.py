@@ -46,28 +46,39 @@ def unpack_reads(packed, length):
     return np.ascontiguousarray(b[:, :length])
 
 
-def unpack_rows(counts8, rows8, escapes=None):
-    """counts8: uint8 [N]; rows8: the dense 8-byte rows (any array of >= sum(counts8) * 8 bytes); escapes: int64 [E, 2]
-    (row index, hi) for rows whose span field is 0xFFFF.  Returns (offsets int64 [N + 1], rows int32 [S, 4])."""
+def unpack_rows(counts8, rows8, escapes=None, row_bytes=8):
+    """counts8: uint8 [N]; rows8: the dense 8-byte rows of genie_find_smems_packed, or the 6-byte rows of
+    genie_find_smems_packed6 (`row_bytes` = 6) -- any array of >= sum(counts8) * row_bytes bytes; escapes: int64 [E, 2]
+    (row index, hi) for rows whose span field is saturated (0xFFFF / 0xFF).  Returns (offsets int64 [N + 1], rows int32 [S, 4])."""
+    if row_bytes not in (6, 8):
+        raise ValueError("row_bytes is 6 or 8")
     counts8 = np.asarray(counts8, np.uint8)
     offsets = np.zeros(len(counts8) + 1, np.int64)
     np.cumsum(counts8, out=offsets[1:])
     total = int(offsets[-1])
-    r = np.frombuffer(np.ascontiguousarray(rows8).view(np.uint8).reshape(-1)[:8 * total].tobytes(), ROW8)
+    raw = np.ascontiguousarray(rows8).view(np.uint8).reshape(-1)[:row_bytes * total]
     rows = np.empty((total, 4), np.int32)
-    rows[:, 0] = r["start"]
-    rows[:, 1] = r["end"]
-    rows[:, 2] = r["lo"].astype(np.int64)
-    rows[:, 3] = r["lo"].astype(np.int64) + r["span"]
-    wide = np.nonzero(r["span"] == 0xFFFF)[0]
+    if row_bytes == 8:
+        r = np.frombuffer(raw.tobytes(), ROW8)
+        lo, span, top = r["lo"].astype(np.int64), r["span"].astype(np.int64), 0xFFFF
+        rows[:, 0] = r["start"]
+        rows[:, 1] = r["end"]
+    else:
+        b = raw.reshape(total, 6).astype(np.int64)
+        lo, span, top = b[:, 2] | b[:, 3] << 8 | b[:, 4] << 16, b[:, 5], 0xFF
+        rows[:, 0] = b[:, 0]
+        rows[:, 1] = b[:, 1]
+    rows[:, 2] = lo
+    rows[:, 3] = lo + span
+    wide = np.nonzero(span == top)[0]
     if len(wide):
         if escapes is None:
-            raise ValueError("rows with span 0xFFFF need the escape list")
+            raise ValueError("rows with a saturated span need the escape list")
         esc = np.asarray(escapes, np.int64).reshape(-1, 2)
         esc = esc[esc[:, 0] < total]
         order = np.argsort(esc[:, 0], kind="stable")
         esc = esc[order]
         if not np.array_equal(esc[:, 0], wide):
-            raise ValueError("escape list does not cover the rows marked 0xFFFF")
+            raise ValueError("escape list does not cover the rows with a saturated span")
         rows[wide, 3] = esc[:, 1]
     return offsets, rows

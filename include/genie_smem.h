@@ -240,6 +240,15 @@ int genie_find_smems_packed(const genie_index *ix, int32_t mode, const uint8_t *
                             void *d_rows8, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
                             void *d_workspace, int64_t workspace_bytes, void *stream);
 
+/* The same with 6-byte rows (another quarter off the bytes that travel back: 66 instead of 88 per 150-base read), for
+ * references below 2^24 bases (GENIE_E_TOO_LONG otherwise): byte 0 start, byte 1 end, bytes 2..4 lo (24 bits, little endian),
+ * byte 5 span = hi - lo, 0xFF meaning "255 or more" (that row's index and hi are on d_escapes).  d_rows6: 2-byte aligned.
+ * Everything else as genie_find_smems_packed; packing.unpack_rows(..., row_bytes=6) is the host side. */
+int genie_find_smems_packed6(const genie_index *ix, int32_t mode, const uint8_t *d_reads2bit, const int32_t *d_lens, int64_t N,
+                             int32_t stride_bytes, int32_t fixed_len, int32_t min_len, uint8_t *d_counts8, uint8_t *d_status8,
+                             void *d_rows6, int64_t out_cap_rows, int64_t *d_totals, int64_t *d_escapes, int64_t cap_escapes,
+                             void *d_workspace, int64_t workspace_bytes, void *stream);
+
 /* Compact the slotted output to CSR: d_offsets[N+1] (exclusive prefix sum of min(count,cap))
  * and d_out[total*4].  d_tmp: scratch of genie_compact_tmp_bytes(N) bytes. */
 int64_t genie_compact_tmp_bytes(int64_t N);

@@ -193,5 +193,13 @@ def test_packing_layouts():
     assert off.tolist() == [0, 2, 2, 3] and rows.tolist() == [[0, 5, 7, 7], [5, 9, 100, 70100], [0, 4, 9, 12]]
     with pytest.raises(ValueError):
         packing.unpack_rows(counts, r8.view(np.uint8), np.zeros((0, 2), np.int64))
+    # the 6-byte rows of genie_find_smems_packed6: start, end, lo (24 bits, little endian), span (0xFF: on the escape list)
+    r6 = np.array([[0, 5, 7, 0, 0, 0], [5, 9, 0x10, 0x27, 0x01, 0xFF], [0, 4, 9, 0, 0, 3]], np.uint8)
+    off, rows = packing.unpack_rows(counts, r6, np.array([[1, 0x12710 + 300]]), row_bytes=6)
+    assert off.tolist() == [0, 2, 2, 3] and rows.tolist() == [[0, 5, 7, 7], [5, 9, 0x12710, 0x12710 + 300], [0, 4, 9, 12]]
+    with pytest.raises(ValueError):
+        packing.unpack_rows(counts, r6, row_bytes=6)
+    with pytest.raises(ValueError):
+        packing.unpack_rows(counts, r6, row_bytes=7)
     with pytest.raises(ValueError):
         packing.unpack_rows(counts, r8.view(np.uint8))

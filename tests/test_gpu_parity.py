@@ -1055,6 +1055,13 @@ def test_packed_entry_point_equals_csr(pkg, oracle_mod):
         off, rows = packing.unpack_rows(c8.cpu().numpy(), r8.cpu().numpy(), esc.cpu().numpy())
         assert np.array_equal(off, want[0].cpu().numpy()) and np.array_equal(rows, want[1].cpu().numpy())
         assert np.array_equal(s8.cpu().numpy().astype(np.int32), want[2].cpu().numpy())
+        # the 6-byte rows of genie_find_smems_packed6 (lo in 24 bits, span in 8 with its own escapes): the same rows again
+        c6, s6, r6, esc6 = ix.find_smems_packed(mode, torch.as_tensor(packing.pack_reads(codes)).cuda(), codes.shape[1],
+                                                lens=None if lens is None else torch.as_tensor(lens).cuda(), min_len=min_len, row_bytes=6)
+        assert r6.shape[1] == 6 and len(esc6) >= len(esc)
+        off6, rows6 = packing.unpack_rows(c6.cpu().numpy(), r6.cpu().numpy(), esc6.cpu().numpy(), row_bytes=6)
+        assert np.array_equal(off6, off) and np.array_equal(rows6, rows) and np.array_equal(s6.cpu().numpy(), s8.cpu().numpy())
+        assert len(esc6) == int((rows[:, 3] - rows[:, 2] >= 255).sum())
         return len(esc)
 
     for ds in ("syn10k_K8", "big100k_K15"):
