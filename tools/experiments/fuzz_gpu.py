@@ -69,7 +69,11 @@ for seed in [int(x) for x in os.environ.get("SEEDS", "1").split()]:
                     c8, s8, r8, esc = ix.find_smems_packed(algo, torch.as_tensor(packing.pack_reads(reads)).cuda(), L,
                                                            lens=None if lens is None else torch.as_tensor(lens).cuda(), min_len=ml)
                     off2, rows2 = packing.unpack_rows(c8.cpu().numpy(), r8.cpu().numpy(), esc.cpu().numpy())
+                    c6, s6, r6, esc6 = ix.find_smems_packed(algo, torch.as_tensor(packing.pack_reads(reads)).cuda(), L,
+                                                            lens=None if lens is None else torch.as_tensor(lens).cuda(), min_len=ml, row_bytes=6)
+                    off6, rows6 = packing.unpack_rows(c6.cpu().numpy(), r6.cpu().numpy(), esc6.cpu().numpy(), row_bytes=6)
                     if not (np.array_equal(off2, offsets.cpu().numpy()) and np.array_equal(rows2, smems.cpu().numpy())
+                            and np.array_equal(off6, off2) and np.array_equal(rows6, rows2)
                             and np.array_equal(s8.cpu().numpy().astype(np.int32), st)):
                         bad += 1
                         print("PACKED MISMATCH seed", seed, "n", len(ref), fmt, "K", K, "L", L, algo)
