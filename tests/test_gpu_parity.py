@@ -1248,3 +1248,27 @@ def test_seventeen_megabase_reference_takes_the_wide_table(pkg, oracle_mod):
     got = ix.sa_interval(pats, lens).cpu().numpy()
     for i in range(1000):
         assert tuple(got[i]) == o.back_prop(pats[i, :lens[i]]), i
+
+
+@pytest.mark.gpu
+def test_scheduling_option_changes_no_result(pkg):
+    """GENIE_OPT_SCHEDULING (fixed shares / no priority rotation in the search and interval kernels: A/B timing only): every value
+    gives the rows of the default, on a batch large enough that every block of the persistent grids has several groups, on long
+    reads and on a ragged tail (N not a multiple of anything)."""
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ix = _index_for(pkg, "syn100k_K15", "lut")
+    cases = [("lut", B.reads_from_ref_fast(d["ref_codes"], 200_003, 150, 77)), ("bwa", B.reads_from_ref(d["ref_codes"], 1501, 700, 78)),
+             ("lut", B.reads_random(4097, 100, 79))]
+    try:
+        for mode, rd in cases:
+            rd = torch.as_tensor(rd).cuda()
+            ix.set_option(pkg._native.OPT_SCHEDULING, 0)
+            want = [t.clone() for t in ix.find_smems(mode, rd)]
+            for v in range(1, 8):
+                ix.set_option(pkg._native.OPT_SCHEDULING, v)
+                got = ix.find_smems(mode, rd)
+                assert all(torch.equal(a, b) for a, b in zip(got, want)), (mode, v)
+    finally:
+        ix.set_option(pkg._native.OPT_SCHEDULING, 0)
