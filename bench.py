@@ -16,7 +16,7 @@ scan of the block sums, interval search writing the offsets and the CSR rows) wi
 (one code per base; generated on the device).  Rank 0 prints ONE JSON line (schema in the task contract) with `roofline`
 and `cpu_baseline`; the default run (config 1) also carries the other BASELINE configs measured in the same process
 (`other_configs`: configs 2, 3 and 4 on one GPU; on N > 1 GPUs config 3, weak, and config 4, the 8 x 10^7-read batch cut
-into N shards, strong -- each record with its own n_gpus / scaling / broadcast_ms) and `value_from_host` (pinned host buffers -> H2D -> call -> D2H through genie_find_smems_packed and,
+into N shards, strong -- each record with its own n_gpus / scaling / broadcast_ms) and `value_from_host` (pinned host buffers -> H2D -> call -> D2H through genie_find_smems_packed6 and,
 beside it, through the CSR entry point: the host link's rate, never `value`).
 
 What the roofline object says: the path moves few bytes and is bound by the L1 miss queue's
