@@ -769,9 +769,8 @@ inline int carve_workspace(void *d_ws, int64_t ws_bytes, int64_t N, const Geomet
     return GENIE_OK;
 }
 
-// long reads: 8 lanes per read once that still leaves a wave for every slot of the chip (measured, from-ref reads:
-// 3 x 10^5 x 500 bases 432 -> 349 us, 75 000 x 2000 bases 438 -> 415 us, but 18 750 x 8000 bases 549 -> 659 us)
-constexpr long long kLongEightLaneReads = 65536;
+// long reads: lanes per read of the traversal kernel by batch size (measured, from-ref reads on the 100 kb reference: below)
+constexpr long long kLongTwoLaneReads = 32768;
 
 struct CsrOut {
     int64_t *offsets = nullptr;      // non-null => write CSR rows to `rows`, else slots
@@ -821,10 +820,14 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     const int tb = 256;
     int reads_per_block = tb;                // of the traversal kernel
     unsigned long long *bsums = csr.offsets ? reinterpret_cast<unsigned long long *>(ws.scan_tmp) : nullptr;
-    if (WIDE) {                              // 8 lanes per read; 16 when the batch is too small to fill the chip otherwise
-        const int lanes = N >= kLongEightLaneReads ? 8 : 16;
-        auto kl = lanes == 8 ? traverse_long_kernel<MODE, 8> : traverse_long_kernel<MODE, 16>;
-        hipLaunchKernelGGL(kl, dim3((unsigned)((N + tb / lanes - 1) / (tb / lanes))), dim3(tb), 0, s, d_lens,
+    if (WIDE) {
+        // lanes per read: 2, each taking eight positions per pass from LDS windows of the row, when the batch is large enough to
+        // give every SIMD several such waves; else 16 lanes of one position each (few reads: the chip needs the lanes).
+        // Measured (from-ref reads, 100 kb reference, traversal kernel alone): 300 000 x 500 bases 329 -> 256 us, 75 000 x 2000
+        // bases 340 -> 270 us with two lanes; 18 750 x 8000 bases 410 us with 16 lanes, 690 us with four lanes of eight positions.
+        const int lanes = N >= kLongTwoLaneReads ? 2 : 16;
+        auto kl = lanes == 2 ? traverse_long_kernel<MODE, 2, 8> : traverse_long_kernel<MODE, 16, 1>;
+        hipLaunchKernelGGL(kl, dim3((unsigned)((N + tb / lanes - 1) / (tb / lanes))), dim3(tb), lanes == 2 ? (tb / lanes) * kLongRowBytes : 0, s, d_lens,
                            (long long)N, fixed_len, min_len, ws.fwd, g.fwd_stride, cnt, reinterpret_cast<uint32_t *>(ws.kj),
                            g.kj_row, csr.offsets ? g.kj_row : cap, st, bsums);
         reads_per_block = tb / lanes;

@@ -1272,3 +1272,34 @@ def test_scheduling_option_changes_no_result(pkg):
                 assert all(torch.equal(a, b) for a, b in zip(got, want)), (mode, v)
     finally:
         ix.set_option(pkg._native.OPT_SCHEDULING, 0)
+
+
+@pytest.mark.gpu
+def test_long_reads_large_batch_against_oracle(pkg, oracle_mod):
+    """Long reads in a batch of 32 768 or more take the two-lanes-per-read traversal (eight positions per lane and pass, the row
+    staged in LDS windows): every row of 40 000 x 300-base and 33 000 x 1000-base reads (from-ref, random, exact copies of the
+    reference -- one match longer than a window -- and ragged lengths) against the CPU oracle, in two modes."""
+    import torch
+    from genie_smem_amd import synth as B
+    d, _ = G.load("syn100k_K15")
+    ref = d["ref_codes"]
+    ix = _index_for(pkg, "syn100k_K15", "lut")
+    o = oracle_mod.Oracle(ref, 15)
+    rng = np.random.default_rng(9)
+    for n_reads, L in ((40_000, 300), (33_000, 1000)):
+        rd = B.reads_from_ref_fast(ref, n_reads, L, 500 + L)
+        rd[:200] = B.reads_random(200, L, 7)
+        for t, p in enumerate(rng.integers(0, len(ref) - L, 100)):           # whole-read matches, some with one substitution
+            rd[200 + t] = ref[p:p + L]
+            if t & 1:
+                rd[200 + t, L // 2] = (rd[200 + t, L // 2] + 1) % 4
+        lens = np.full(n_reads, L, np.int32)
+        lens[300:2300] = rng.integers(15, L + 1, 2000)
+        for mode in ("lut", "bwa"):
+            off, rows, st = ix.find_smems(mode, torch.as_tensor(rd).cuda(), lens=torch.as_tensor(lens).cuda(), min_len=1)
+            assert int(st.abs().sum().item()) == 0
+            off, rows = off.cpu().numpy(), rows.cpu().numpy()
+            sel = np.concatenate([np.arange(0, 2400), rng.integers(2400, n_reads, 1600)])
+            counts, want = o.find_smems_batch(mode, rd[sel], nthreads=16, lens=lens[sel])
+            for t, r in enumerate(sel):
+                assert rows[off[r]:off[r + 1]].tolist() == want[t, :counts[t]].tolist(), (L, mode, int(r))

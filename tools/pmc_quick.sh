@@ -7,7 +7,7 @@ import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(match_table\w*|traverse_kernel|interval_kernel)", r["Kernel_Name"])
+        m = re.search(r"(match_table\w*|traverse_\w*kernel|interval_kernel)", r["Kernel_Name"])
         if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v) / 1e6, 2) for c, v in sorted(d.items())})
