@@ -10,6 +10,8 @@ P = lambda t: C.c_void_p(t.data_ptr())
 VARS = [int(x) for x in os.environ.get("VARS", "0 4 2 6 3 7").split()]
 CASES = ((100_000, 1_000_000, "fromref", 150), (1_000_000, 4_000_000, "fromref", 150), (100_000, 1_000_000, "random", 150),
          (100_000, 300_000, "fromref", 500), (100_000, 75_000, "fromref", 2000), (100_000, 18_750, "fromref", 8000))
+if os.environ.get("CASE"):
+    c = os.environ["CASE"].split(","); CASES = ((int(c[0]), int(c[1]), c[2], int(c[3])),)
 for n, N, kind, L in CASES[int(os.environ.get("FIRST_CASE", "0")):]:
     ref = synth.synth_ref(n, n)
     ix = g.GenieIndex.build(ref, 15); ix.train_rmi([1000]); ix = ix.to("cuda")
