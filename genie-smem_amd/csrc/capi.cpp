@@ -410,7 +410,7 @@ int genie_index_set_option(genie_index *ix, int32_t option, int32_t value)
     case GENIE_OPT_SEARCH_ALL: ix->opt_search_all = value != 0; return GENIE_OK;
     case GENIE_OPT_GROUP_POSITIONS: ix->opt_group_positions = value > 0 ? value : 0; return GENIE_OK;
     case GENIE_OPT_SEARCH_ONLY: ix->opt_search_only = value != 0; if (!value) ix->opt_debug = 0; return GENIE_OK;
-    case GENIE_OPT_SCHEDULING: ix->opt_scheduling = value & 7; return GENIE_OK;
+    case GENIE_OPT_SCHEDULING: ix->opt_scheduling = value & 15; return GENIE_OK;
     case GENIE_OPT_SEARCH_STAGES_OFF: ix->opt_debug = ix->opt_search_only ? (value & 63) : 0; return GENIE_OK;
     case GENIE_OPT_SEARCH_BLOCKS_PER_CU: ix->opt_search_blocks_per_cu = value > 0 ? value : 0; return GENIE_OK;
     default: return GENIE_E_INVALID;

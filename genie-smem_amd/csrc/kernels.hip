@@ -40,6 +40,28 @@ __device__ __forceinline__ void set_wave_priority(int i)
     }
 }
 
+// Ask for the 64-byte lines of [p, p + bytes) through the SCALAR cache (p, bytes wave-uniform; p inside a live allocation).
+// A CU keeps ~64 vector-memory misses in flight and a line that comes from HBM / the Infinity Cache holds one of those slots
+// for ~1800 cycles, nine times as long as an L2 hit -- the streamed lines of a persistent kernel (its next inputs) therefore
+// cost it more slot time than their count suggests.  Scalar loads reach the L2 by another path (the scalar data cache's own
+// miss handling), so a wave that asks for its NEXT iteration's lines this way finds them in the L2 when its vector loads
+// come.  The loaded dwords are dropped; the wait is part of the block because the destination register must not be reused
+// while a load is in flight (the wave waits here instead of at its first vector load).
+__device__ __forceinline__ void scalar_touch_lines(const void *p, uint32_t bytes)
+{
+    uint32_t d, off;
+    asm volatile("s_mov_b32 %[off], 0\n"
+                 "1:\n\t"
+                 "s_load_dword %[d], %[p], %[off]\n\t"
+                 "s_add_u32 %[off], %[off], 64\n\t"
+                 "s_cmp_lt_u32 %[off], %[n]\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [d] "=&s"(d), [off] "=&s"(off)
+                 : [p] "s"(reinterpret_cast<uint64_t>(p) & ~3ull), [n] "s"(bytes)
+                 : "scc", "memory");
+}
+
 // LDS traffic between lanes of ONE wave: the LDS executes a wave's instructions in order, so
 // only the compiler has to be stopped from reordering.
 __device__ __forceinline__ void wave_lds_fence()
@@ -855,7 +877,7 @@ int launch_pipeline(const genie_index *ix, const Geometry &g, const uint8_t *d_r
     const long long need_c = (N + kIvWaves * 4 * kIvUnroll - 1) / (kIvWaves * 4 * kIvUnroll);
     if (grid_c > need_c) grid_c = need_c;
     RowEscapes esc{nullptr, nullptr, 0};
-    const int sched_c = (ix->opt_scheduling >> 2) | cus << 8;        // bit 0: no priority rotation; bits 8..: CUs (blocks per round)
+    const int sched_c = ((ix->opt_scheduling >> 2) & 1) | cus << 8;  // bit 0: no priority rotation; bits 8..: CUs (blocks per round)
     if (csr.packed) {
         esc.count = reinterpret_cast<unsigned long long *>(csr.offsets) + 1;
         esc.list = reinterpret_cast<long long *>(csr.escapes);

@@ -280,7 +280,8 @@ int genie_locate(const genie_index *ix, const int32_t *d_lohi, int32_t stride, i
  *   records, 32 fwd rows; the stage ablation of DESIGN.md section 4 (tools/ka_sweep.sh).
  * GENIE_OPT_SCHEDULING (default 0; A/B timing, results unchanged): bit mask -- 1: the match-statistics kernel gives every
  *   wave a fixed share of the read groups instead of handing them out per block; 2: its waves keep one issue priority
- *   instead of rotating it; 4: the same for the interval kernel. */
+ *   instead of rotating it; 4: the same for the interval kernel; 8: the match-statistics kernels do not ask for their next
+ *   group's input rows through the scalar cache ahead of time. */
 enum { GENIE_OPT_SEARCH_ALL = 2, GENIE_OPT_GROUP_POSITIONS = 4, GENIE_OPT_SEARCH_ONLY = 5, GENIE_OPT_SEARCH_BLOCKS_PER_CU = 6,
        GENIE_OPT_SEARCH_STAGES_OFF = 7, GENIE_OPT_SCHEDULING = 8 };
 int genie_index_set_option(genie_index *ix, int32_t option, int32_t value);

@@ -1266,7 +1266,7 @@ def test_scheduling_option_changes_no_result(pkg):
             rd = torch.as_tensor(rd).cuda()
             ix.set_option(pkg._native.OPT_SCHEDULING, 0)
             want = [t.clone() for t in ix.find_smems(mode, rd)]
-            for v in range(1, 8):
+            for v in range(1, 16):
                 ix.set_option(pkg._native.OPT_SCHEDULING, v)
                 got = ix.find_smems(mode, rd)
                 assert all(torch.equal(a, b) for a, b in zip(got, want)), (mode, v)
