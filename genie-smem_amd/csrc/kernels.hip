@@ -101,6 +101,18 @@ struct QRecs {
     const RefRec *p;
     __device__ __forceinline__ uint64_t win(int pos) const { return rwin(p, pos); }
 };
+// QPlain: plain 64-bit words in global memory (short reads since round 3: half the bytes of the records): a window is one
+// 16-byte load at an 8-byte-aligned address.
+struct QPlain {
+    const uint64_t *p;
+    __device__ __forceinline__ uint64_t win(int pos) const
+    {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        typedef u64x2 u64x2_a8 __attribute__((aligned(8)));
+        const u64x2 v = *reinterpret_cast<const u64x2_a8 *>(p + (pos >> 5));
+        return funnel(v.x, v.y, (pos & 31) * 2);
+    }
+};
 
 // ------------------------------------------------------------------ prefix directory (LDS)
 // dir[x] = number of SA rows whose suffix is smaller than the P-mer string x.  Rows whose
@@ -690,9 +702,9 @@ struct Geometry {
     int max_len;
     int fwd_stride;  // bytes per fwd[] row in the workspace
     int fwd_lds;     // bytes per fwd[] row in K_B's LDS copy (narrow): an odd number of dwords
-    int qp_recs;     // 16-byte packed-read records per read in the workspace
-    int qp_stride;   // records per read SLOT: short reads keep the head of the (count, pairs) row behind the records,
-                     // slots padded to whole 64-byte lines (K_C's count, pairs and window come from one line)
+    int qp_recs;     // 16-byte pieces of the packed read per read in the workspace (long reads: overlapping records {w[i], w[i+1]};
+                     // short reads: plain words, two per piece)
+    int qp_stride;   // 16-byte units per read SLOT: short reads keep the head of the (count, pairs) row behind the packed read
     int kj_row;      // emitted-pair entries per read
 };
 
@@ -700,7 +712,9 @@ inline void shape_for(int max_len, Geometry *g)
 {
     g->max_len = max_len;
     g->wide = max_len > 255;
-    g->qp_recs = g->wide ? (max_len + 31) / 32 : 2 * std::max(1, (max_len + 63) / 64);
+    // long reads: overlapping records {w[i], w[i+1]}, one per 32 bases; short reads: plain words in 16-byte pieces, enough of them
+    // for a window that starts up to 8 bases behind the read (the zero padding K_A and K_C both see)
+    g->qp_recs = g->wide ? (max_len + 31) / 32 : ((max_len + 8 + 31) / 32 + 1 + 1) / 2;
     // rows are multiples of 16 bytes (K_A copies them out 16 bytes per lane); K_B's LDS rows are an odd number of
     // dwords, so that lanes reading the same offset of their own rows hit distinct banks
     g->fwd_stride = g->wide ? ((max_len * 2) + 15) & ~15 : std::max(16, (max_len + 15) & ~15);
@@ -708,7 +722,7 @@ inline void shape_for(int max_len, Geometry *g)
     if ((dw & 1) == 0) dw++;
     g->fwd_lds = dw * 4;
     g->kj_row = (std::max(max_len, 1) + 1 + 7) & ~7;      // entry 0 = the count
-    g->qp_stride = g->wide ? g->qp_recs : ((g->qp_recs * 16 + kPairHeadWords * 8 + 63) & ~63) / 16;
+    g->qp_stride = g->wide ? g->qp_recs : g->qp_recs + kPairHeadWords * 8 / 16;      // 80 bytes at 150 bases: four slots = five lines
 }
 
 int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, Geometry *g)

@@ -158,7 +158,7 @@ def test_workspace_rows_and_index_create_ex_arguments():
     import ctypes as C
     import genie_smem_amd as pkg
     w = pkg.GenieIndex.workspace_shape(150)
-    assert w == {"fwd_stride": 160, "qp_recs": 6, "kj_row_bytes": 2 * 152}
+    assert w == {"fwd_stride": 160, "qp_recs": 3, "kj_row_bytes": 2 * 152}
     w = pkg.GenieIndex.workspace_shape(2000)
     assert w["fwd_stride"] == 4000 and w["qp_recs"] == 63
     lib = pkg._native.lib()
