@@ -388,7 +388,7 @@ def roofline_of(w, offcfg=()):
     roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_read": search_bytes,
             "kernel_ms_avg": kern_ms_avg, "kernel_ms_min": float(np.min(w["kern_ms"])),
-            "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, packed-read records, "
+            "definition": "achieved = compulsory HBM bytes of this kernel (reads in; fwd rows, the packed read as plain words, "
                           "status out) / its time; the kernel is bound by random L1->L2 requests and VALU issue, "
                           "not by HBM (see `binding`)",
             "step": {"kernels": "match statistics + traversal + scan of the block sums + interval search -> offsets and CSR rows",
@@ -407,6 +407,10 @@ def roofline_of(w, offcfg=()):
         roof["traffic"] = dom.get("hbm_bytes")
         hbm_step = sum(k.get("hbm_bytes", 0.0) for k in ks.values())
         roof["traffic_raw"] = dom.get("hbm_bytes_raw")
+        roof["traffic_note"] = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, the guide's gfx950 correction; this kernel asks for its "
+                                "input through the scalar cache (64-byte s_load fetches, which FETCH_SIZE counts in full, where it counted "
+                                "the streamed vector reads at half), so the correction overstates it: traffic_raw = FETCH_SIZE + WRITE_SIZE "
+                                "is the closer figure")
         roof["counters_tag"] = ctr.get("tag")
         roof["step"].update({"hbm_measured_bytes": hbm_step, "hbm_measured_bytes_raw": sum(k.get("hbm_bytes_raw", 0.0) for k in ks.values()),
                              "hbm_note": "FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH HBM correction; an upper bound for narrow accesses); _raw = "

@@ -205,7 +205,8 @@ int genie_seed_lookup(const genie_index *ix, int32_t mode, const uint8_t *d_kmer
  * the kernels of the pipeline). */
 int64_t genie_find_smems_workspace_bytes(int64_t N, int32_t max_len);
 /* Per-read rows of that workspace, for traffic accounting: out[0] = bytes of a matching-statistics (fwd) row,
- * out[1] = 16-byte packed-read records, out[2] = 0 (reserved), out[3] = bytes of the emitted
+ * out[1] = 16-byte pieces of the packed read (reads of up to 255 bases: plain 64-bit words, two per piece; longer: overlapping
+ * records {w[i], w[i+1]}), out[2] = 0 (reserved), out[3] = bytes of the emitted
  * (count, (start, end) pairs) row. */
 int genie_find_smems_workspace_rows(int32_t max_len, int32_t *row_bytes4);
 int genie_find_smems(const genie_index *ix, int32_t mode, const uint8_t *d_reads, const int32_t *d_lens,

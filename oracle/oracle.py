@@ -87,7 +87,7 @@ class Oracle:
         self._h = lib().orc_index_build(_u8(codes), self.n, self.K)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and callable(lib):          # (module globals are gone at interpreter shutdown)
             lib().orc_index_free(self._h)
             self._h = None
 
