@@ -421,10 +421,10 @@ def roofline_of(w, offcfg=()):
             cycles = dom.get("GRBM_GUI_ACTIVE", 0) / ctr.get("xcds", 8)            # kernel duration in shader cycles
             lat = dom.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / req if req else None
             roof["binding"] = {
-                "resource": "L1 miss concurrency x latency: a CU keeps ~64 L1->L2 read requests in flight (one 64-byte line per table "
-                            "entry), so the kernel's time is requests x mean latency / (64 x CUs) -- on a table that fits the L2 the "
-                            "latency is the L2's ~200 cycles and vector-instruction issue is the other limit; on one that does not, the "
-                            "mean latency (and so the time) follows the L2 MISSES, each a trip through the fabric",
+                "resource": "vector-instruction issue and L1 miss handling: on a table that fits the L2 (100 kb) VALU issue is the first limit "
+                            "(valu_issue_share) with ~60 L1->L2 read requests in flight per CU at the L2's ~180 cycles (one 64-byte line per "
+                            "table entry); on one that does not (1 Mb) the mean latency -- and with it the time -- follows the L2 MISSES, each "
+                            "a trip through the fabric (~120 requests in flight per CU, the L1 reporting pending stalls 4/5 of the time)",
                 "l2_read_requests_per_read": req / n_reads,
                 "mean_request_latency_cycles": lat,
                 "requests_in_flight_per_cu": (dom.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / (cycles * 256)) if cycles else None,
