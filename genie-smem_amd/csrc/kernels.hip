@@ -41,11 +41,11 @@ __device__ __forceinline__ void set_wave_priority(int i)
 }
 
 // Ask for the 64-byte lines of [p, p + bytes) through the SCALAR cache (p, bytes wave-uniform; p inside a live allocation).
-// A CU keeps ~64 vector-memory misses in flight and a line that comes from HBM / the Infinity Cache holds one of those slots
-// for ~1800 cycles, nine times as long as an L2 hit -- the streamed lines of a persistent kernel (its next inputs) therefore
-// cost it more slot time than their count suggests.  Scalar loads reach the L2 by another path (the scalar data cache's own
-// miss handling), so a wave that asks for its NEXT iteration's lines this way finds them in the L2 when its vector loads
-// come.  The loaded dwords are dropped; the wait is part of the block because the destination register must not be reused
+// A CU's L1 handles a bounded amount of miss time (it reports "pending" stalls two thirds of a lookup kernel's life) and a
+// line that comes from HBM / the Infinity Cache is in flight for 1300-1800 cycles, seven to nine times as long as an L2 hit --
+// the streamed lines of a persistent kernel (its next inputs) therefore cost it more than their count suggests.  Scalar
+// loads reach the L2 by another path (the scalar data cache's own miss handling), so a wave that asks for its NEXT
+// iteration's lines this way finds them in the L2 when its vector loads come ("streamed lines").  The loaded dwords are dropped; the wait is part of the block because the destination register must not be reused
 // while a load is in flight (the wave waits here instead of at its first vector load).
 __device__ __forceinline__ void scalar_touch_lines(const void *p, uint32_t bytes)
 {
