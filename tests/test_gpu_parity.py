@@ -298,7 +298,9 @@ def test_fixed_length_slot_layouts(pkg, oracle_mod, algo, search_all):
 
 def _slot_layout_cases(pkg, ix, o, d, algo):
     from genie_smem_amd import synth as B
-    for L in (15, 20, 31, 32, 33, 64, 65, 70, 96, 97, 128, 129, 131, 134, 150, 160, 161, 192, 193, 200, 224, 225, 255):
+    # (.. 24/25, 56/57, .. 248/249: where the packed read in the workspace gains a 16-byte piece)
+    for L in (15, 20, 24, 25, 31, 32, 33, 56, 57, 64, 65, 70, 88, 89, 96, 97, 120, 121, 128, 129, 131, 134, 150, 152, 153, 160, 161,
+              184, 185, 192, 193, 200, 216, 217, 224, 225, 248, 249, 255):
         n_reads = 301
         rd = B.reads_from_ref(d["ref_codes"], n_reads, L, 1000 + L)
         rd[7, L // 2] = 5                       # flagged read as the second of a pair
