@@ -743,7 +743,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
         const int ml = std::max(max_len, 1);
         const int grp = ix->opt_group_positions > 0 ? ix->opt_group_positions / ml : kMtTarget / ml;
         g->grp = std::max(1, std::min(std::min(kMtMaxG, kWave / mt_pack_dwords(ml) * 4), grp));
-        g->lds = wpb * mt_wave_bytes(g->grp, ml, g->qp_recs, g->fwd_stride) + 16;     // + the block's group counter
+        g->lds = wpb * mt_wave_bytes(g->grp, ml, g->qp_recs, g->fwd_stride) + 16 + mt_quad_table_bytes(g->grp, ml);   // + the block's group counter and quad table
         per_block = (long long)wpb * g->grp;
     }
     if (g->lds > lds_cap) return GENIE_E_TOO_LONG;
