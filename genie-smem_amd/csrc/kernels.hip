@@ -731,7 +731,7 @@ int plan_find_smems(const genie_index *ix, int mode, int max_len, long long N, G
     const int lds_cap = 160 * 1024;
     shape_for(max_len, g);
     const int cus = ix->num_cus > 0 ? ix->num_cus : 256;
-    const int wpb = 8;                       // waves per block: nothing block-wide in LDS, no barrier
+    const int wpb = 8;                       // waves per block (block-wide in LDS: the group counter and the quad table)
     long long per_block;
     if (g->wide) {
         g->grp = 1;
