@@ -16,7 +16,7 @@ if kind == "random":
 else:
     reads = torch.as_tensor(synth.reads_from_ref_fast(ref, N, L, 1002)).cuda()
 lib = g._native.lib()
-for k, v in ((4, "GROUP_POS"), (5, "SEARCH_ONLY"), (2, "SEARCH_ALL"), (6, "BPC"), (7, "DBG")):
+for k, v in ((4, "GROUP_POS"), (5, "SEARCH_ONLY"), (2, "SEARCH_ALL"), (6, "BPC"), (7, "DBG"), (8, "SCHED")):
     if os.environ.get(v):
         ix.set_option(k, int(os.environ[v]))
 status = torch.empty(N, dtype=torch.int32, device="cuda"); offsets = torch.empty(N + 1, dtype=torch.int64, device="cuda")
